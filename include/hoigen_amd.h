@@ -1,0 +1,197 @@
+/*
+ * hoigen_amd — C ABI of the MI355X (gfx950) hot path of HOIGen.
+ *
+ * The reference (soberguo/HOIGen) has no FFI: its boundary is Python duck-typing on nn.Module
+ * attributes.  This header is the boundary a binding for that path would target;
+ * `hoigen_amd/_lib.py` is the ctypes binding and `hoigen_amd/{clip,model,vae}.py` present the
+ * reference's own Python signatures on top of it.  Every entry point names the reference
+ * interface it replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ *  - All data pointers are DEVICE pointers to contiguous row-major buffers owned by the caller.
+ *  - Calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream).
+ *  - Return value: 0 on success, negative hg_status on failure; text via hg_last_error().
+ *  - One context per device per process; a context is not re-entrant (the reference is
+ *    single-threaded per process, one process per GPU: main_tip_finetune.py:1205-1208).
+ *  - The library allocates device memory only in hg_create / hg_load_* / on workspace growth
+ *    (monotonic); steady-state calls do not allocate or synchronise (hipGraph-capturable).
+ *  - Arithmetic: fp16 MFMA operands, fp32 accumulation; residual stream, LayerNorm statistics and
+ *    softmax in fp32.  Inference only (no autograd).
+ */
+#ifndef HOIGEN_AMD_H
+#define HOIGEN_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hg_ctx hg_ctx;
+
+typedef enum {
+    HG_OK = 0,
+    HG_ERR_INVALID = -1,     /* bad argument / unsupported shape            */
+    HG_ERR_HIP = -2,         /* a HIP runtime call failed                   */
+    HG_ERR_NOT_LOADED = -3,  /* weights for this entry point not loaded yet */
+    HG_ERR_OOM = -4
+} hg_status;
+
+typedef enum { HG_F32 = 0, HG_F16 = 1 } hg_dtype;
+
+/* A weight tensor handed to hg_load_*: device pointer + element type.  ptr == NULL means absent. */
+typedef struct {
+    const void* ptr;
+    int32_t dtype; /* hg_dtype */
+} hg_tensor;
+
+/* ResidualAttentionBlock parameters — clipnet/model.py:167-188; state-dict keys
+ * `{prefix}.resblocks.{i}.{attn.in_proj_weight,...}`.  Linear weights are [out,in]. */
+typedef struct {
+    hg_tensor in_proj_weight;  /* [3D, D]  rows q|k|v */
+    hg_tensor in_proj_bias;    /* [3D]                */
+    hg_tensor out_proj_weight; /* [D, D]              */
+    hg_tensor out_proj_bias;   /* [D]                 */
+    hg_tensor ln_1_weight, ln_1_bias; /* [D] */
+    hg_tensor c_fc_weight;     /* [4D, D] */
+    hg_tensor c_fc_bias;       /* [4D]    */
+    hg_tensor c_proj_weight;   /* [D, 4D] */
+    hg_tensor c_proj_bias;     /* [D]     */
+    hg_tensor ln_2_weight, ln_2_bias; /* [D] */
+} hg_block_weights;
+
+/* TransformerDecoderLayer(64, nhead=2, ffn=128) as used by the adapter —
+ * CLIP_models_adapter_prior2.py:27-72 (forward_post; norm1 exists but is unused). */
+typedef struct {
+    hg_tensor attn_in_proj_weight;  /* [3d, d] */
+    hg_tensor attn_in_proj_bias;    /* [3d]    */
+    hg_tensor attn_out_proj_weight; /* [d, d]  */
+    hg_tensor attn_out_proj_bias;   /* [d]     */
+    hg_tensor linear1_weight, linear1_bias; /* [2d, d], [2d] */
+    hg_tensor linear2_weight, linear2_bias; /* [d, 2d], [d]  */
+    hg_tensor norm2_weight, norm2_bias;     /* [d] */
+    hg_tensor norm3_weight, norm3_bias;     /* [d] */
+} hg_decoder_layer_weights;
+
+/* Adapter — CLIP_models_adapter_prior2.py:142-203; keys `...resblocks.{i}.adaptermlp.*`. */
+typedef struct {
+    int32_t present;                 /* 0: this block has no adapter (adapter_pos, :958-967) */
+    int32_t bottleneck;              /* 64 */
+    hg_tensor scale;                 /* [D]   */
+    hg_tensor down_proj_weight, down_proj_bias; /* [d, D], [d] */
+    hg_tensor up_proj_weight, up_proj_bias;     /* [D, d], [D] */
+    hg_decoder_layer_weights prior_layer;       /* mhsa_layers.0 (memory = prior tokens) */
+    hg_decoder_layer_weights self_layer;        /* mhsa          (memory = down itself)  */
+} hg_adapter_weights;
+
+/* VisionTransformer — clipnet/model.py:202-236 (variant A) and
+ * CLIP_models_adapter_prior2.py:471-506 (variant C). */
+typedef struct {
+    int32_t width, layers, heads, patch_size, input_resolution, output_dim;
+    hg_tensor conv1_weight;          /* [D, 3, p, p]     */
+    hg_tensor class_embedding;       /* [D]              */
+    hg_tensor positional_embedding;  /* [g*g+1, D]       */
+    hg_tensor ln_pre_weight, ln_pre_bias, ln_post_weight, ln_post_bias; /* [D] */
+    hg_tensor proj;                  /* [D, E]  (x @ proj) */
+    const hg_block_weights* blocks;      /* [layers] */
+    const hg_adapter_weights* adapters;  /* NULL or [layers] */
+} hg_vit_weights;
+
+/* Text tower of CLIP — clipnet/model.py:282-292,339-352. */
+typedef struct {
+    int32_t width, layers, heads, context_length, vocab_size, output_dim;
+    hg_tensor token_embedding;       /* [V, D]  */
+    hg_tensor positional_embedding;  /* [L, D]  */
+    hg_tensor ln_final_weight, ln_final_bias; /* [D] */
+    hg_tensor text_projection;       /* [D, E]  (x @ text_projection) */
+    const hg_block_weights* blocks;  /* [layers] */
+} hg_text_weights;
+
+/* CoOp-VAE — main_coop_vae.py:261-296.  Any of the two halves may be absent (ptr NULL). */
+typedef struct {
+    int32_t dim, enc_hidden, gen_hidden;       /* 512, 2048, 4096 */
+    hg_tensor enc_w0, enc_b0;                  /* Encoder.net.0     [2048,512],[2048] */
+    hg_tensor enc_mean_w, enc_mean_b;          /* Encoder.mean      [512,2048],[512]  */
+    hg_tensor enc_logvar_w, enc_logvar_b;      /* Encoder.log_var   [512,2048],[512]  */
+    hg_tensor gen_w0, gen_b0;                  /* Generator.net.0   [4096,512],[4096] */
+    hg_tensor gen_w2, gen_b2;                  /* Generator.net.2   [512,4096],[512]  */
+} hg_vae_weights;
+
+/* mlp_net(512,512,512) — finetune_ship.py:302-314 / main_tip_finetune.py:313-324. */
+typedef struct {
+    int32_t in_dim, hidden_dim, out_dim;
+    hg_tensor w0, b0, w2, b2, w4, b4;
+} hg_mlp_weights;
+
+#define HG_MAX_SLOTS 4 /* independent VAE / mlp_net weight sets: hoi, human, object (+1) */
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+hg_ctx* hg_create(int device);                 /* NULL on failure (no HIP device)               */
+void hg_destroy(hg_ctx*);
+const char* hg_last_error(hg_ctx*);            /* valid until the next call on the context      */
+const char* hg_version(void);
+
+/* ---- weights (replace nn.Module.load_state_dict / build_model: clipnet/model.py:395-432,
+ *      CLIP_models_adapter_prior2.py:934-984).  Weights are copied/converted; the caller may free
+ *      its tensors afterwards.  Loading again replaces the previous set. -------------------------- */
+int hg_load_vit(hg_ctx*, const hg_vit_weights*);
+int hg_load_text(hg_ctx*, const hg_text_weights*);
+int hg_load_vae(hg_ctx*, int slot, const hg_vae_weights*);
+int hg_load_mlp(hg_ctx*, int slot, const hg_mlp_weights*);
+/* Refresh only the adapter tensors of an already-loaded ViT (they are the trainable part:
+ * main_tip_finetune.py:955-962). */
+int hg_update_adapters(hg_ctx*, const hg_adapter_weights* adapters, int layers);
+
+/* ---- image tower --------------------------------------------------------------------------- */
+/* CLIP.encode_image / VisionTransformer.forward, variant A (clipnet/model.py:219-236,336-337):
+ * x [B,3,R,R] fp32 NCHW -> out [B,E] fp32. */
+int hg_encode_image(hg_ctx*, const float* x_nchw, int B, float* out, void* stream);
+/* Variant C VisionTransformer.forward(x, prior) (CLIP_models_adapter_prior2.py:489-506).
+ * priors [B,N,64] fp32 and mask [B,N] uint8 (1 = padded key) or both NULL / N == 0 for prior=None.
+ * out_global [B,E]; out_local [B,E,g,g] (NCHW).  Blocks without a loaded adapter behave as A. */
+int hg_encode_image_prior(hg_ctx*, const float* x_nchw, const float* priors, const uint8_t* mask,
+                          int B, int N, float* out_global, float* out_local_nchw, void* stream);
+/* Test hook: as hg_encode_image, additionally copies the CLS row of the residual stream after
+ * ln_pre and after every block into trace [(layers+1), B, D] fp32. */
+int hg_encode_image_trace(hg_ctx*, const float* x_nchw, int B, float* out, float* trace, void* stream);
+
+/* ---- text tower ---------------------------------------------------------------------------- */
+/* CLIP.encode_text (clipnet/model.py:339-352): ids [T,L] int32 (L <= context_length), zero padded,
+ * EOT = largest id per row -> out [T,E] fp32.  `trunc` != 0 runs the causal tower only on the first
+ * max(EOT)+1 positions (identical selected outputs; SURVEY.md §5 "Long-context"). */
+int hg_encode_text_ids(hg_ctx*, const int32_t* ids, int T, int L, float* out, int trunc, void* stream);
+/* TextEncoder.forward(prompts, tokenized_prompts) (main_coop_vae.py:54-63): prompts [R,L,D] fp32
+ * already embedded, eot_idx [R] int32 = tokenized_prompts.argmax(-1) -> out [R,E] fp32. */
+int hg_encode_text_embeds(hg_ctx*, const float* prompts, const int32_t* eot_idx, int R, int L,
+                          float* out, int trunc, void* stream);
+/* token_embedding(ids) (clipnet/model.py:340): ids [n] int32 -> out [n,D] fp32 (exact gather). */
+int hg_token_embedding(hg_ctx*, const int32_t* ids, int n, float* out, void* stream);
+
+/* ---- CoOp-VAE ------------------------------------------------------------------------------ */
+/* Encoder -> reparameterise(eps given) -> Generator (main_coop_vae.py:444-448).
+ * x, eps [R,dim] fp32 -> mean, logvar, z, bias [R,dim] fp32 (any output may be NULL). */
+int hg_vae_forward(hg_ctx*, int slot, const float* x, const float* eps, int R, float* mean,
+                   float* logvar, float* z, float* bias, void* stream);
+/* Generator.forward (main_coop_vae.py:293-296): z [R,dim] -> bias [R,dim]. */
+int hg_generator(hg_ctx*, int slot, const float* z, int R, float* bias, void* stream);
+/* mlp_net.forward (finetune_ship.py:312-314). */
+int hg_mlp_net(hg_ctx*, int slot, const float* x, int R, float* out, void* stream);
+/* PromptLearner_*.forward (main_coop_vae.py:119-128): prefix [C,1,D], suffix [C,L-1-n_ctx,D],
+ * ctx [n_ctx,D], bias [R,D], target [R] int32 -> prompts [R,L,D]; all fp32. */
+int hg_assemble_prompts(hg_ctx*, const float* prefix, const float* suffix, const float* ctx,
+                        const float* bias, const int32_t* target, int R, int C, int L, int n_ctx,
+                        int D, float* prompts, void* stream);
+/* x / x.norm(dim=-1, keepdim=True) (main_coop_vae.py:438,466); in == out allowed. */
+int hg_l2_normalize(hg_ctx*, const float* x, int R, int D, float* out, void* stream);
+/* vae_loss forward value (main_coop_vae.py:300-303) -> loss[1] fp32. */
+int hg_vae_loss(hg_ctx*, const float* recon, const float* x, const float* mean, const float* logvar,
+                int R, int D, float* loss, void* stream);
+
+/* ---- introspection for bench.py (no reference counterpart) --------------------------------- */
+/* Name of the dominant GEMM kernel and FLOPs per launch for the last hg_encode_image call. */
+int hg_workspace_bytes(hg_ctx*, uint64_t* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HOIGEN_AMD_H */
