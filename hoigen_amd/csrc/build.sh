@@ -1,0 +1,16 @@
+#!/bin/bash
+# Build libhoigen_amd.so for gfx950 (cross-compiles without a GPU).
+set -e
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wall -Wno-unused-function -ffp-contract=fast"
+OBJS=""
+for f in hg_gemm hg_attn hg_elem hg_adapter hg_api; do
+  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ hg_kernels.h -nt $f.o ] || [ hg_common.h -nt $f.o ] || [ ../../include/hoigen_amd.h -nt $f.o ]; then
+    $HIPCC $FLAGS -c $f.hip -o $f.o &
+  fi
+  OBJS="$OBJS $f.o"
+done
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC $OBJS -o libhoigen_amd.so
+echo "built $(pwd)/libhoigen_amd.so"

@@ -1,0 +1,955 @@
+// C ABI of hoigen_amd (include/hoigen_amd.h): context, weight conversion into the device layout,
+// grow-only workspace and the launch sequences of the three hot paths (image tower, text tower,
+// CoOp-VAE).  Host code only; kernels live in hg_gemm.hip / hg_attn.hip / hg_elem.hip / hg_adapter.hip.
+//
+// Device data layout:
+//   residual stream x   fp32 [M, D]      M = n_seq * L rows (token-major, sequence-contiguous)
+//   h / att / fc        fp16 [M, D|4D]   MFMA A operands (K contiguous)
+//   qkv                 fp16 [M, 3D]     q|k|v column blocks, head h = columns 64h..64h+63
+//   linear weights      fp16 [N, K]      exactly nn.Linear's [out, in] -> both GEMM operands K-contiguous
+//   proj/text_projection fp16 [E, D]     transposed once at load ([D,E] in the state dict)
+//   biases, LN affine, embeddings, positional: fp32
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/hoigen_amd.h"
+#include "hg_kernels.h"
+
+using namespace hg;
+
+namespace {
+
+struct Buf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct BlockW {
+    half_t *w_qkv, *w_out, *w_fc, *w_proj;
+    float *b_qkv, *b_out, *b_fc, *b_proj, *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+};
+
+struct AdapterW {
+    bool present = false;
+    int d = 0;
+    half_t* down_w = nullptr;  // [128 (padded), D]
+    float* down_b = nullptr;   // [128]
+    half_t* up_w = nullptr;    // [D, 64]
+    float* up_b = nullptr;
+    float* scale = nullptr;
+    float* dl[2][12] = {};     // see AdapterDev
+};
+
+struct Vit {
+    bool loaded = false;
+    int D = 0, layers = 0, heads = 0, patch = 0, res = 0, grid = 0, L = 0, E = 0, Kp = 0;
+    half_t* w_patch = nullptr;
+    float *cls = nullptr, *pos = nullptr, *lnpre_w = nullptr, *lnpre_b = nullptr, *lnpost_w = nullptr,
+          *lnpost_b = nullptr;
+    half_t* w_projT = nullptr;
+    std::vector<BlockW> blocks;
+    std::vector<AdapterW> adapters;
+    std::vector<void*> owned, owned_adapters;
+};
+
+struct Text {
+    bool loaded = false;
+    int D = 0, layers = 0, heads = 0, ctx = 0, vocab = 0, E = 0;
+    float *tok = nullptr, *pos = nullptr, *lnf_w = nullptr, *lnf_b = nullptr;
+    half_t* w_projT = nullptr;
+    std::vector<BlockW> blocks;
+    std::vector<void*> owned;
+};
+
+struct Vae {
+    bool enc = false, gen = false;
+    int dim = 0, eh = 0, gh = 0;
+    half_t *e_w0 = nullptr, *e_wml = nullptr, *g_w0 = nullptr, *g_w2 = nullptr;
+    float *e_b0 = nullptr, *e_bml = nullptr, *g_b0 = nullptr, *g_b2 = nullptr;
+    std::vector<void*> owned;
+};
+
+struct Mlp {
+    bool loaded = false;
+    int in = 0, hid = 0, out = 0;
+    half_t *w0 = nullptr, *w2 = nullptr, *w4 = nullptr;
+    float *b0 = nullptr, *b2 = nullptr, *b4 = nullptr;
+    std::vector<void*> owned;
+};
+
+}  // namespace
+
+struct hg_ctx {
+    int device = 0;
+    std::string err;
+    Vit vit;
+    Text text;
+    Vae vae[HG_MAX_SLOTS];
+    Mlp mlp[HG_MAX_SLOTS];
+    // workspace (grow-only)
+    Buf x, h, qkv, att, fc, head16, tok32, small, i32, ad32, ad16, adkv;
+    int max_chunk_img = 256;
+    int max_chunk_txt = 640;
+    int max_chunk_rows = 32768;
+    // live per-kernel timing for bench.py (hg_profile_begin/end): hipEvent pairs around every launch
+    // of one GEMM epilogue class, on the stream the kernel is launched on
+    int prof_class = -1;
+    std::vector<hipEvent_t> prof_ev;
+    size_t prof_n = 0;
+    double prof_flops = 0.0;
+    int prof_M = 0, prof_N = 0, prof_K = 0;
+};
+
+namespace {
+
+int fail(hg_ctx* c, int code, const char* fmt, ...) {
+    char tmp[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(tmp, sizeof tmp, fmt, ap);
+    va_end(ap);
+    if (c) c->err = tmp;
+    return code;
+}
+
+#define HG_HIP(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(c, HG_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                        __LINE__);                                                                     \
+    } while (0)
+
+int ensure(hg_ctx* c, Buf& b, size_t bytes) {
+    if (b.bytes >= bytes) return HG_OK;
+    if (b.p) HG_HIP(hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+    bytes = (bytes + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) return fail(c, HG_ERR_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    HG_HIP(hipMemset(b.p, 0, bytes));
+    b.bytes = bytes;
+    return HG_OK;
+}
+
+void free_all(std::vector<void*>& v) {
+    for (void* p : v) (void)hipFree(p);
+    v.clear();
+}
+
+// ---- weight conversion helpers (synchronous; load time only) ------------------------------------
+int dev_alloc(hg_ctx* c, std::vector<void*>& owned, size_t bytes, void** out) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+    if (e != hipSuccess) return fail(c, HG_ERR_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    owned.push_back(p);
+    *out = p;
+    return HG_OK;
+}
+
+int as_f16(hg_ctx* c, std::vector<void*>& owned, const hg_tensor& t, size_t n, half_t** out, const char* name) {
+    if (!t.ptr) return fail(c, HG_ERR_INVALID, "missing tensor %s", name);
+    void* p;
+    int rc = dev_alloc(c, owned, n * 2, &p);
+    if (rc) return rc;
+    if (t.dtype == HG_F16) HG_HIP(hipMemcpy(p, t.ptr, n * 2, hipMemcpyDeviceToDevice));
+    else if (t.dtype == HG_F32) HG_HIP(launch_f32_to_f16((const float*)t.ptr, (half_t*)p, n, 0));
+    else return fail(c, HG_ERR_INVALID, "bad dtype for %s", name);
+    *out = (half_t*)p;
+    return HG_OK;
+}
+
+int as_f32(hg_ctx* c, std::vector<void*>& owned, const hg_tensor& t, size_t n, float** out, const char* name) {
+    if (!t.ptr) return fail(c, HG_ERR_INVALID, "missing tensor %s", name);
+    void* p;
+    int rc = dev_alloc(c, owned, n * 4, &p);
+    if (rc) return rc;
+    if (t.dtype == HG_F32) HG_HIP(hipMemcpy(p, t.ptr, n * 4, hipMemcpyDeviceToDevice));
+    else if (t.dtype == HG_F16) HG_HIP(launch_f16_to_f32((const half_t*)t.ptr, (float*)p, n, 0));
+    else return fail(c, HG_ERR_INVALID, "bad dtype for %s", name);
+    *out = (float*)p;
+    return HG_OK;
+}
+
+// [rows, cols] -> fp16 [cols, rows]
+int as_f16_T(hg_ctx* c, std::vector<void*>& owned, const hg_tensor& t, int rows, int cols, half_t** out,
+             const char* name) {
+    if (!t.ptr) return fail(c, HG_ERR_INVALID, "missing tensor %s", name);
+    void* p;
+    int rc = dev_alloc(c, owned, (size_t)rows * cols * 2, &p);
+    if (rc) return rc;
+    HG_HIP(launch_transpose_to_f16(t.ptr, t.dtype, (half_t*)p, rows, cols, 0));
+    *out = (half_t*)p;
+    return HG_OK;
+}
+
+// fp32 [rows, cols] -> fp32 [cols, rows] via host (tiny adapter matrices)
+int as_f32_T(hg_ctx* c, std::vector<void*>& owned, const hg_tensor& t, int rows, int cols, float** out,
+             const char* name) {
+    float* tmp;
+    std::vector<void*> scratch;
+    int rc = as_f32(c, scratch, t, (size_t)rows * cols, &tmp, name);
+    if (rc) { free_all(scratch); return rc; }
+    std::vector<float> h((size_t)rows * cols), ht((size_t)rows * cols);
+    hipError_t e = hipMemcpy(h.data(), tmp, h.size() * 4, hipMemcpyDeviceToHost);
+    free_all(scratch);
+    if (e != hipSuccess) return fail(c, HG_ERR_HIP, "hipMemcpy D2H failed for %s", name);
+    for (int r = 0; r < rows; ++r)
+        for (int k = 0; k < cols; ++k) ht[(size_t)k * rows + r] = h[(size_t)r * cols + k];
+    void* p;
+    rc = dev_alloc(c, owned, ht.size() * 4, &p);
+    if (rc) return rc;
+    HG_HIP(hipMemcpy(p, ht.data(), ht.size() * 4, hipMemcpyHostToDevice));
+    *out = (float*)p;
+    return HG_OK;
+}
+
+int load_blocks(hg_ctx* c, std::vector<void*>& owned, const hg_block_weights* src, int layers, int D,
+                std::vector<BlockW>& dst) {
+    if (!src) return fail(c, HG_ERR_INVALID, "blocks == NULL");
+    dst.assign(layers, BlockW{});
+    for (int i = 0; i < layers; ++i) {
+        const hg_block_weights& s = src[i];
+        BlockW& b = dst[i];
+        int rc = 0;
+        rc |= as_f16(c, owned, s.in_proj_weight, (size_t)3 * D * D, &b.w_qkv, "attn.in_proj_weight");
+        rc |= as_f32(c, owned, s.in_proj_bias, (size_t)3 * D, &b.b_qkv, "attn.in_proj_bias");
+        rc |= as_f16(c, owned, s.out_proj_weight, (size_t)D * D, &b.w_out, "attn.out_proj.weight");
+        rc |= as_f32(c, owned, s.out_proj_bias, D, &b.b_out, "attn.out_proj.bias");
+        rc |= as_f32(c, owned, s.ln_1_weight, D, &b.ln1_w, "ln_1.weight");
+        rc |= as_f32(c, owned, s.ln_1_bias, D, &b.ln1_b, "ln_1.bias");
+        rc |= as_f16(c, owned, s.c_fc_weight, (size_t)4 * D * D, &b.w_fc, "mlp.c_fc.weight");
+        rc |= as_f32(c, owned, s.c_fc_bias, (size_t)4 * D, &b.b_fc, "mlp.c_fc.bias");
+        rc |= as_f16(c, owned, s.c_proj_weight, (size_t)4 * D * D, &b.w_proj, "mlp.c_proj.weight");
+        rc |= as_f32(c, owned, s.c_proj_bias, D, &b.b_proj, "mlp.c_proj.bias");
+        rc |= as_f32(c, owned, s.ln_2_weight, D, &b.ln2_w, "ln_2.weight");
+        rc |= as_f32(c, owned, s.ln_2_bias, D, &b.ln2_b, "ln_2.bias");
+        if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
+    }
+    return HG_OK;
+}
+
+int load_decoder_layer(hg_ctx* c, std::vector<void*>& owned, const hg_decoder_layer_weights& s, int d,
+                       float* dl[12]) {
+    // 0 WqT [d,d] (in->out), 1 bq, 2 WkT, 3 bk, 4 WvT, 5 bv : split of in_proj;  6 WoT, 7 bo ... see below
+    std::vector<void*> scratch;
+    float* inw;
+    float* inb;
+    int rc = as_f32(c, scratch, s.attn_in_proj_weight, (size_t)3 * d * d, &inw, "adapter in_proj_weight");
+    if (!rc) rc = as_f32(c, scratch, s.attn_in_proj_bias, (size_t)3 * d, &inb, "adapter in_proj_bias");
+    if (rc) { free_all(scratch); return rc; }
+    for (int part = 0; part < 3 && !rc; ++part) {
+        hg_tensor wt{inw + (size_t)part * d * d, HG_F32};
+        hg_tensor bt{inb + (size_t)part * d, HG_F32};
+        rc = as_f32_T(c, owned, wt, d, d, &dl[part], "adapter q/k/v weight");
+        if (!rc) rc = as_f32(c, owned, bt, d, &dl[3 + part], "adapter q/k/v bias");
+    }
+    free_all(scratch);
+    if (rc) return rc;
+    rc |= as_f32_T(c, owned, s.attn_out_proj_weight, d, d, &dl[6], "adapter out_proj.weight");
+    rc |= as_f32(c, owned, s.attn_out_proj_bias, d, &dl[7], "adapter out_proj.bias");
+    // norm2 | norm3 packed: [w2, b2, w3, b3] (4*d)
+    {
+        float* p;
+        int r2 = dev_alloc(c, owned, (size_t)4 * d * 4, (void**)&p);
+        if (r2) return r2;
+        const hg_tensor* ts[4] = {&s.norm2_weight, &s.norm2_bias, &s.norm3_weight, &s.norm3_bias};
+        for (int k = 0; k < 4; ++k) {
+            float* t;
+            std::vector<void*> sc;
+            int r3 = as_f32(c, sc, *ts[k], d, &t, "adapter norm");
+            if (r3) { free_all(sc); return r3; }
+            hipError_t e = hipMemcpy(p + (size_t)k * d, t, (size_t)d * 4, hipMemcpyDeviceToDevice);
+            free_all(sc);
+            if (e != hipSuccess) return fail(c, HG_ERR_HIP, "memcpy norm failed");
+        }
+        dl[8] = p;
+    }
+    rc |= as_f32_T(c, owned, s.linear1_weight, 2 * d, d, &dl[9], "adapter linear1.weight");   // [d, 2d]
+    rc |= as_f32(c, owned, s.linear1_bias, (size_t)2 * d, &dl[10], "adapter linear1.bias");
+    // linear2: weight^T [2d, d] followed by bias [d]
+    {
+        float* w2t;
+        std::vector<void*> sc;
+        int r2 = as_f32_T(c, sc, s.linear2_weight, d, 2 * d, &w2t, "adapter linear2.weight");
+        float* b2 = nullptr;
+        if (!r2) r2 = as_f32(c, sc, s.linear2_bias, d, &b2, "adapter linear2.bias");
+        float* p = nullptr;
+        if (!r2) r2 = dev_alloc(c, owned, ((size_t)2 * d * d + d) * 4, (void**)&p);
+        if (!r2) {
+            hipError_t e = hipMemcpy(p, w2t, (size_t)2 * d * d * 4, hipMemcpyDeviceToDevice);
+            if (e == hipSuccess) e = hipMemcpy(p + (size_t)2 * d * d, b2, (size_t)d * 4, hipMemcpyDeviceToDevice);
+            if (e != hipSuccess) r2 = fail(c, HG_ERR_HIP, "memcpy linear2 failed");
+        }
+        free_all(sc);
+        if (r2) return r2;
+        dl[11] = p;
+    }
+    return rc ? (rc < 0 ? rc : HG_ERR_INVALID) : HG_OK;
+}
+
+int load_adapters(hg_ctx* c, const hg_adapter_weights* src, int layers) {
+    Vit& v = c->vit;
+    free_all(v.owned_adapters);
+    v.adapters.assign(v.layers, AdapterW{});
+    if (!src) return HG_OK;
+    if (layers != v.layers) return fail(c, HG_ERR_INVALID, "adapter layer count %d != %d", layers, v.layers);
+    const int D = v.D;
+    for (int i = 0; i < layers; ++i) {
+        const hg_adapter_weights& s = src[i];
+        if (!s.present) continue;
+        if (s.bottleneck != 64) return fail(c, HG_ERR_INVALID, "adapter bottleneck must be 64 (got %d)", s.bottleneck);
+        AdapterW& a = v.adapters[i];
+        const int d = 64;
+        a.d = d;
+        std::vector<void*>& own = v.owned_adapters;
+        // down_proj padded to 128 output rows (the GEMM tile is 128 wide); rows 64.. are zero
+        void* p;
+        int rc = dev_alloc(c, own, (size_t)128 * D * 2, &p);
+        if (rc) return rc;
+        HG_HIP(hipMemset(p, 0, (size_t)128 * D * 2));
+        a.down_w = (half_t*)p;
+        if (!s.down_proj_weight.ptr) return fail(c, HG_ERR_INVALID, "missing adapter down_proj.weight");
+        if (s.down_proj_weight.dtype == HG_F16)
+            HG_HIP(hipMemcpy(p, s.down_proj_weight.ptr, (size_t)d * D * 2, hipMemcpyDeviceToDevice));
+        else HG_HIP(launch_f32_to_f16((const float*)s.down_proj_weight.ptr, a.down_w, (size_t)d * D, 0));
+        rc = dev_alloc(c, own, 128 * 4, &p);
+        if (rc) return rc;
+        HG_HIP(hipMemset(p, 0, 128 * 4));
+        a.down_b = (float*)p;
+        {
+            float* t;
+            std::vector<void*> sc;
+            rc = as_f32(c, sc, s.down_proj_bias, d, &t, "adapter down_proj.bias");
+            if (!rc && hipMemcpy(p, t, d * 4, hipMemcpyDeviceToDevice) != hipSuccess) rc = HG_ERR_HIP;
+            free_all(sc);
+            if (rc) return rc;
+        }
+        rc |= as_f16(c, own, s.up_proj_weight, (size_t)D * d, &a.up_w, "adapter up_proj.weight");
+        rc |= as_f32(c, own, s.up_proj_bias, D, &a.up_b, "adapter up_proj.bias");
+        rc |= as_f32(c, own, s.scale, D, &a.scale, "adapter scale");
+        if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
+        rc = load_decoder_layer(c, own, s.prior_layer, d, a.dl[0]);
+        if (rc) return rc;
+        rc = load_decoder_layer(c, own, s.self_layer, d, a.dl[1]);
+        if (rc) return rc;
+        a.present = true;
+    }
+    HG_HIP(hipDeviceSynchronize());
+    return HG_OK;
+}
+
+inline size_t rup(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+hipError_t gemm(hg_ctx* c, int epi, const GemmArgs& g, hipStream_t s) {
+    const bool prof = (c->prof_class == epi) && (2 * c->prof_n + 1 < c->prof_ev.size()) &&
+                      (c->prof_M == 0 || (c->prof_M == g.M && c->prof_N == g.N && c->prof_K == g.K));
+    if (prof) {
+        hipError_t e = hipEventRecord(c->prof_ev[2 * c->prof_n], s);
+        if (e != hipSuccess) return e;
+    }
+    hipError_t e = launch_gemm(epi, g, s);
+    if (prof && e == hipSuccess) {
+        e = hipEventRecord(c->prof_ev[2 * c->prof_n + 1], s);
+        if (c->prof_n == 0) { c->prof_flops = gemm_flops(g); c->prof_M = g.M; c->prof_N = g.N; c->prof_K = g.K; }
+        c->prof_n++;
+    }
+    return e;
+}
+
+// ---- one transformer tower over the residual stream in c->x ------------------------------------------
+struct AdapterCall {
+    const float* priors = nullptr;   // [n_seq, N, 64] or null
+    const uint8_t* mask = nullptr;
+    int N = 0;
+    bool enabled = false;
+};
+
+int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const AdapterCall& ac, hipStream_t s);
+
+int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, int D, int heads, bool causal,
+               hipStream_t s, float* trace, int trace_stride, const AdapterCall* ac) {
+    const int M = n_seq * L;
+    float* x = (float*)c->x.p;
+    half_t* h = (half_t*)c->h.p;
+    half_t* qkv = (half_t*)c->qkv.p;
+    half_t* att = (half_t*)c->att.p;
+    half_t* fc = (half_t*)c->fc.p;
+    for (size_t i = 0; i < blocks.size(); ++i) {
+        const BlockW& b = blocks[i];
+        if (ac && ac->enabled && c->vit.adapters.size() > i && c->vit.adapters[i].present) {
+            int rc = run_adapter(c, c->vit.adapters[i], n_seq, L, D, *ac, s);
+            if (rc) return rc;
+        }
+        HG_HIP(launch_layernorm_f16(x, b.ln1_w, b.ln1_b, h, M, D, nullptr, 0, 1, s));
+        GemmArgs g{};
+        g.A = h; g.lda = D; g.W = b.w_qkv; g.bias = b.b_qkv; g.out = qkv; g.ldc = 3 * D; g.M = M; g.N = 3 * D; g.K = D;
+        HG_HIP(gemm(c, EPI_BIAS_F16, g, s));
+        HG_HIP(launch_attention(qkv, att, n_seq, L, heads, causal, s));
+        g = GemmArgs{};
+        g.A = att; g.lda = D; g.W = b.w_out; g.bias = b.b_out; g.out = x; g.ldc = D; g.M = M; g.N = D; g.K = D;
+        HG_HIP(gemm(c, EPI_BIAS_RESID_F32, g, s));
+        HG_HIP(launch_layernorm_f16(x, b.ln2_w, b.ln2_b, h, M, D, nullptr, 0, 1, s));
+        g = GemmArgs{};
+        g.A = h; g.lda = D; g.W = b.w_fc; g.bias = b.b_fc; g.out = fc; g.ldc = 4 * D; g.M = M; g.N = 4 * D; g.K = D;
+        HG_HIP(gemm(c, EPI_BIAS_QGELU_F16, g, s));
+        g = GemmArgs{};
+        g.A = fc; g.lda = 4 * D; g.W = b.w_proj; g.bias = b.b_proj; g.out = x; g.ldc = D; g.M = M; g.N = D; g.K = 4 * D;
+        HG_HIP(gemm(c, EPI_BIAS_RESID_F32, g, s));
+        if (trace) HG_HIP(launch_copy_rows(x, trace + (size_t)(i + 1) * trace_stride, n_seq, L, D, s));
+    }
+    return HG_OK;
+}
+
+int ensure_tower_ws(hg_ctx* c, int M, int D) {
+    const size_t Mp = rup(M, 128);
+    int rc = 0;
+    rc |= ensure(c, c->x, Mp * D * 4);
+    rc |= ensure(c, c->h, Mp * D * 2);
+    rc |= ensure(c, c->qkv, Mp * 3 * D * 2);
+    rc |= ensure(c, c->att, Mp * D * 2);
+    rc |= ensure(c, c->fc, Mp * 4 * D * 2);
+    return rc ? HG_ERR_OOM : HG_OK;
+}
+
+int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const AdapterCall& ac, hipStream_t s) {
+    const int M = n_seq * L;
+    float* x = (float*)c->x.p;
+    half_t* h = (half_t*)c->h.p;
+    const size_t Mp = rup(M, 128);
+    int rc = ensure(c, c->ad32, Mp * 128 * 4);
+    if (!rc) rc = ensure(c, c->ad16, Mp * 64 * 2);
+    const int Nmem = ac.priors ? ac.N : L;
+    if (!rc) rc = ensure(c, c->adkv, (size_t)n_seq * Nmem * 64 * 4 * 2);
+    if (rc) return rc;
+    // down = relu(down_proj(x))  (CLIP_models_adapter_prior2.py:184-185)
+    HG_HIP(launch_f32_to_f16(x, h, (size_t)M * D, s));
+    GemmArgs g{};
+    g.A = h; g.lda = D; g.W = a.down_w; g.bias = a.down_b; g.out = c->ad32.p; g.ldc = 128; g.M = M; g.N = 128; g.K = D;
+    HG_HIP(gemm(c, EPI_BIAS_RELU_F32, g, s));
+    AdapterDev ad{};
+    ad.down_w = a.down_w; ad.down_b = a.down_b; ad.up_w = a.up_w; ad.up_b = a.up_b; ad.scale = a.scale;
+    for (int k = 0; k < 2; ++k)
+        for (int j = 0; j < 12; ++j) ad.dl[k][j] = a.dl[k][j];
+    // post-norm decoder layer over the 64-wide bottleneck (adapter...:186-200)
+    HG_HIP(launch_adapter_decoder((const float*)c->ad32.p, ad, ac.priors, ac.mask, n_seq, L, ac.priors ? ac.N : 0,
+                                  (float*)c->adkv.p, (half_t*)c->ad16.p, s));
+    // x += up_proj(.) * scale   (adapter...:201-202, :456)
+    g = GemmArgs{};
+    g.A = (const half_t*)c->ad16.p; g.lda = 64; g.W = a.up_w; g.bias = a.up_b; g.pos = a.scale; g.out = x; g.ldc = D;
+    g.M = M; g.N = D; g.K = 64;
+    HG_HIP(gemm(c, EPI_SCALE_RESID_F32, g, s));
+    return HG_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* hg_version(void) { return "hoigen_amd 0.1 (gfx950)"; }
+
+hg_ctx* hg_create(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return nullptr;
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    hg_ctx* c = new hg_ctx();
+    c->device = device;
+    return c;
+}
+
+void hg_destroy(hg_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    free_all(c->vit.owned);
+    free_all(c->vit.owned_adapters);
+    free_all(c->text.owned);
+    for (auto& v : c->vae) free_all(v.owned);
+    for (auto& m : c->mlp) free_all(m.owned);
+    Buf* bufs[] = {&c->x, &c->h, &c->qkv, &c->att, &c->fc, &c->head16, &c->tok32, &c->small, &c->i32,
+                   &c->ad32, &c->ad16, &c->adkv};
+    for (Buf* b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
+    delete c;
+}
+
+const char* hg_last_error(hg_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int hg_profile_begin(hg_ctx* c, int gemm_class, int max_launches) {
+    if (!c || max_launches < 0) return HG_ERR_INVALID;
+    HG_HIP(hipSetDevice(c->device));
+    for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
+    c->prof_ev.clear();
+    c->prof_n = 0; c->prof_flops = 0.0; c->prof_M = c->prof_N = c->prof_K = 0;
+    c->prof_class = gemm_class;
+    if (gemm_class < 0) return HG_OK;
+    c->prof_ev.resize((size_t)2 * max_launches);
+    for (auto& e : c->prof_ev) HG_HIP(hipEventCreate(&e));
+    return HG_OK;
+}
+
+int hg_profile_end(hg_ctx* c, double* avg_ms, int32_t* launches, double* flops_per_launch, int32_t* mnk) {
+    if (!c || !avg_ms || !launches || !flops_per_launch) return HG_ERR_INVALID;
+    HG_HIP(hipSetDevice(c->device));
+    double tot = 0.0;
+    for (size_t i = 0; i < c->prof_n; ++i) {
+        HG_HIP(hipEventSynchronize(c->prof_ev[2 * i + 1]));
+        float ms = 0.f;
+        HG_HIP(hipEventElapsedTime(&ms, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+        tot += ms;
+    }
+    *launches = (int32_t)c->prof_n;
+    *avg_ms = c->prof_n ? tot / (double)c->prof_n : 0.0;
+    *flops_per_launch = c->prof_flops;
+    if (mnk) { mnk[0] = c->prof_M; mnk[1] = c->prof_N; mnk[2] = c->prof_K; }
+    for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
+    c->prof_ev.clear();
+    c->prof_class = -1;
+    c->prof_n = 0;
+    return HG_OK;
+}
+
+int hg_workspace_bytes(hg_ctx* c, uint64_t* bytes) {
+    if (!c || !bytes) return HG_ERR_INVALID;
+    Buf* bufs[] = {&c->x, &c->h, &c->qkv, &c->att, &c->fc, &c->head16, &c->tok32, &c->small, &c->i32,
+                   &c->ad32, &c->ad16, &c->adkv};
+    uint64_t t = 0;
+    for (Buf* b : bufs) t += b->bytes;
+    *bytes = t;
+    return HG_OK;
+}
+
+// ---- weights --------------------------------------------------------------------------------------------
+int hg_load_vit(hg_ctx* c, const hg_vit_weights* w) {
+    if (!c || !w) return HG_ERR_INVALID;
+    HG_HIP(hipSetDevice(c->device));
+    Vit& v = c->vit;
+    free_all(v.owned);
+    free_all(v.owned_adapters);
+    v = Vit{};
+    const int D = w->width, p = w->patch_size;
+    if (D <= 0 || D % 128 || w->heads * 64 != D)
+        return fail(c, HG_ERR_INVALID, "vision width must be a multiple of 128 with heads = width/64 (got %d, %d)", D,
+                    w->heads);
+    if (p <= 0 || p % 8 || w->input_resolution % p || (3 * p * p) % 64)
+        return fail(c, HG_ERR_INVALID, "unsupported patch size %d / resolution %d", p, w->input_resolution);
+    if (w->output_dim <= 0 || w->output_dim % 128)
+        return fail(c, HG_ERR_INVALID, "output_dim must be a multiple of 128 (got %d)", w->output_dim);
+    v.D = D; v.layers = w->layers; v.heads = w->heads; v.patch = p; v.res = w->input_resolution;
+    v.grid = v.res / p; v.L = v.grid * v.grid + 1; v.E = w->output_dim; v.Kp = 3 * p * p;
+    if (v.L > 224) return fail(c, HG_ERR_INVALID, "at most 224 tokens per image supported (got %d)", v.L);
+    int rc = 0;
+    rc |= as_f16(c, v.owned, w->conv1_weight, (size_t)D * v.Kp, &v.w_patch, "visual.conv1.weight");
+    rc |= as_f32(c, v.owned, w->class_embedding, D, &v.cls, "visual.class_embedding");
+    rc |= as_f32(c, v.owned, w->positional_embedding, (size_t)v.L * D, &v.pos, "visual.positional_embedding");
+    rc |= as_f32(c, v.owned, w->ln_pre_weight, D, &v.lnpre_w, "visual.ln_pre.weight");
+    rc |= as_f32(c, v.owned, w->ln_pre_bias, D, &v.lnpre_b, "visual.ln_pre.bias");
+    rc |= as_f32(c, v.owned, w->ln_post_weight, D, &v.lnpost_w, "visual.ln_post.weight");
+    rc |= as_f32(c, v.owned, w->ln_post_bias, D, &v.lnpost_b, "visual.ln_post.bias");
+    rc |= as_f16_T(c, v.owned, w->proj, D, v.E, &v.w_projT, "visual.proj");
+    if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
+    rc = load_blocks(c, v.owned, w->blocks, v.layers, D, v.blocks);
+    if (rc) return rc;
+    rc = load_adapters(c, w->adapters, v.layers);
+    if (rc) return rc;
+    HG_HIP(hipDeviceSynchronize());
+    v.loaded = true;
+    return HG_OK;
+}
+
+int hg_update_adapters(hg_ctx* c, const hg_adapter_weights* adapters, int layers) {
+    if (!c) return HG_ERR_INVALID;
+    if (!c->vit.loaded) return fail(c, HG_ERR_NOT_LOADED, "hg_load_vit first");
+    HG_HIP(hipSetDevice(c->device));
+    HG_HIP(hipDeviceSynchronize());
+    return load_adapters(c, adapters, layers);
+}
+
+int hg_load_text(hg_ctx* c, const hg_text_weights* w) {
+    if (!c || !w) return HG_ERR_INVALID;
+    HG_HIP(hipSetDevice(c->device));
+    Text& t = c->text;
+    free_all(t.owned);
+    t = Text{};
+    const int D = w->width;
+    if (D <= 0 || D % 128 || w->heads * 64 != D)
+        return fail(c, HG_ERR_INVALID, "text width must be a multiple of 128 with heads = width/64 (got %d, %d)", D,
+                    w->heads);
+    if (w->context_length > 224) return fail(c, HG_ERR_INVALID, "context_length > 224 unsupported");
+    if (w->output_dim <= 0 || w->output_dim % 128) return fail(c, HG_ERR_INVALID, "output_dim %% 128 != 0");
+    t.D = D; t.layers = w->layers; t.heads = w->heads; t.ctx = w->context_length; t.vocab = w->vocab_size;
+    t.E = w->output_dim;
+    int rc = 0;
+    rc |= as_f32(c, t.owned, w->token_embedding, (size_t)t.vocab * D, &t.tok, "token_embedding.weight");
+    rc |= as_f32(c, t.owned, w->positional_embedding, (size_t)t.ctx * D, &t.pos, "positional_embedding");
+    rc |= as_f32(c, t.owned, w->ln_final_weight, D, &t.lnf_w, "ln_final.weight");
+    rc |= as_f32(c, t.owned, w->ln_final_bias, D, &t.lnf_b, "ln_final.bias");
+    rc |= as_f16_T(c, t.owned, w->text_projection, D, t.E, &t.w_projT, "text_projection");
+    if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
+    rc = load_blocks(c, t.owned, w->blocks, t.layers, D, t.blocks);
+    if (rc) return rc;
+    HG_HIP(hipDeviceSynchronize());
+    t.loaded = true;
+    return HG_OK;
+}
+
+int hg_load_vae(hg_ctx* c, int slot, const hg_vae_weights* w) {
+    if (!c || !w || slot < 0 || slot >= HG_MAX_SLOTS) return HG_ERR_INVALID;
+    HG_HIP(hipSetDevice(c->device));
+    Vae& v = c->vae[slot];
+    free_all(v.owned);
+    v = Vae{};
+    v.dim = w->dim; v.eh = w->enc_hidden; v.gh = w->gen_hidden;
+    if (v.dim <= 0 || v.dim % 128) return fail(c, HG_ERR_INVALID, "vae dim must be a multiple of 128");
+    int rc = 0;
+    if (w->enc_w0.ptr) {
+        if (v.eh <= 0 || v.eh % 128) return fail(c, HG_ERR_INVALID, "enc_hidden must be a multiple of 128");
+        rc |= as_f16(c, v.owned, w->enc_w0, (size_t)v.eh * v.dim, &v.e_w0, "Encoder.net.0.weight");
+        rc |= as_f32(c, v.owned, w->enc_b0, v.eh, &v.e_b0, "Encoder.net.0.bias");
+        // mean | log_var stacked into one [2*dim, eh] GEMM operand
+        void* p;
+        rc |= dev_alloc(c, v.owned, (size_t)2 * v.dim * v.eh * 2, &p);
+        if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
+        v.e_wml = (half_t*)p;
+        std::vector<void*> sc;
+        half_t *m, *l;
+        rc |= as_f16(c, sc, w->enc_mean_w, (size_t)v.dim * v.eh, &m, "Encoder.mean.weight");
+        rc |= as_f16(c, sc, w->enc_logvar_w, (size_t)v.dim * v.eh, &l, "Encoder.log_var.weight");
+        if (!rc) {
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpy(v.e_wml, m, (size_t)v.dim * v.eh * 2, hipMemcpyDeviceToDevice);
+            (void)hipMemcpy(v.e_wml + (size_t)v.dim * v.eh, l, (size_t)v.dim * v.eh * 2, hipMemcpyDeviceToDevice);
+        }
+        free_all(sc);
+        rc |= dev_alloc(c, v.owned, (size_t)2 * v.dim * 4, &p);
+        if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
+        v.e_bml = (float*)p;
+        float *bm, *bl;
+        rc |= as_f32(c, sc, w->enc_mean_b, v.dim, &bm, "Encoder.mean.bias");
+        rc |= as_f32(c, sc, w->enc_logvar_b, v.dim, &bl, "Encoder.log_var.bias");
+        if (!rc) {
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpy(v.e_bml, bm, (size_t)v.dim * 4, hipMemcpyDeviceToDevice);
+            (void)hipMemcpy(v.e_bml + v.dim, bl, (size_t)v.dim * 4, hipMemcpyDeviceToDevice);
+        }
+        free_all(sc);
+        if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
+        v.enc = true;
+    }
+    if (w->gen_w0.ptr) {
+        if (v.gh <= 0 || v.gh % 128) return fail(c, HG_ERR_INVALID, "gen_hidden must be a multiple of 128");
+        rc |= as_f16(c, v.owned, w->gen_w0, (size_t)v.gh * v.dim, &v.g_w0, "Generator.net.0.weight");
+        rc |= as_f32(c, v.owned, w->gen_b0, v.gh, &v.g_b0, "Generator.net.0.bias");
+        rc |= as_f16(c, v.owned, w->gen_w2, (size_t)v.dim * v.gh, &v.g_w2, "Generator.net.2.weight");
+        rc |= as_f32(c, v.owned, w->gen_b2, v.dim, &v.g_b2, "Generator.net.2.bias");
+        if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
+        v.gen = true;
+    }
+    HG_HIP(hipDeviceSynchronize());
+    return HG_OK;
+}
+
+int hg_load_mlp(hg_ctx* c, int slot, const hg_mlp_weights* w) {
+    if (!c || !w || slot < 0 || slot >= HG_MAX_SLOTS) return HG_ERR_INVALID;
+    HG_HIP(hipSetDevice(c->device));
+    Mlp& m = c->mlp[slot];
+    free_all(m.owned);
+    m = Mlp{};
+    m.in = w->in_dim; m.hid = w->hidden_dim; m.out = w->out_dim;
+    if (m.in % 64 || m.hid % 128 || m.out % 128 || m.in <= 0) return fail(c, HG_ERR_INVALID, "mlp_net dims must be multiples of 128");
+    int rc = 0;
+    rc |= as_f16(c, m.owned, w->w0, (size_t)m.hid * m.in, &m.w0, "mlp.net.0.weight");
+    rc |= as_f32(c, m.owned, w->b0, m.hid, &m.b0, "mlp.net.0.bias");
+    rc |= as_f16(c, m.owned, w->w2, (size_t)m.hid * m.hid, &m.w2, "mlp.net.2.weight");
+    rc |= as_f32(c, m.owned, w->b2, m.hid, &m.b2, "mlp.net.2.bias");
+    rc |= as_f16(c, m.owned, w->w4, (size_t)m.out * m.hid, &m.w4, "mlp.net.4.weight");
+    rc |= as_f32(c, m.owned, w->b4, m.out, &m.b4, "mlp.net.4.bias");
+    if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
+    HG_HIP(hipDeviceSynchronize());
+    m.loaded = true;
+    return HG_OK;
+}
+
+// ---- image tower ------------------------------------------------------------------------------------------
+static int encode_image_impl(hg_ctx* c, const float* x_nchw, const float* priors, const uint8_t* mask, int B, int N,
+                             float* out, float* out_local, float* trace, bool variant_c, hipStream_t s) {
+    if (!c) return HG_ERR_INVALID;
+    Vit& v = c->vit;
+    if (!v.loaded) return fail(c, HG_ERR_NOT_LOADED, "hg_load_vit has not been called");
+    if (B < 0 || !x_nchw || !out) return fail(c, HG_ERR_INVALID, "bad arguments to encode_image");
+    if (variant_c && !out_local) return fail(c, HG_ERR_INVALID, "out_local == NULL");
+    if (priors && (N <= 0 || !mask)) return fail(c, HG_ERR_INVALID, "priors given but N <= 0 or mask == NULL");
+    HG_HIP(hipSetDevice(c->device));
+    const int D = v.D, L = v.L, G = L - 1, E = v.E;
+    const size_t img = (size_t)3 * v.res * v.res;
+    for (int b0 = 0; b0 < B; b0 += c->max_chunk_img) {
+        const int Bc = (B - b0 < c->max_chunk_img) ? B - b0 : c->max_chunk_img;
+        const int M = Bc * L;
+        int rc = ensure_tower_ws(c, M, D);
+        if (!rc) rc = ensure(c, c->head16, rup(variant_c ? M : Bc, 128) * D * 2);
+        if (!rc && variant_c) rc = ensure(c, c->tok32, (size_t)M * E * 4);
+        if (!rc) rc = ensure(c, c->fc, rup((size_t)Bc * G, 128) * (v.Kp > 4 * D ? v.Kp : 4 * D) * 2);
+        if (rc) return rc;
+        float* x = (float*)c->x.p;
+        half_t* patches = (half_t*)c->fc.p;
+        // conv1 as GEMM over the patch matrix; epilogue scatters to token rows 1.. and adds pos
+        HG_HIP(launch_im2col(x_nchw + (size_t)b0 * img, patches, Bc, v.res, v.patch, s));
+        GemmArgs g{};
+        g.A = patches; g.lda = v.Kp; g.W = v.w_patch; g.bias = nullptr; g.out = x; g.ldc = D;
+        g.M = Bc * G; g.N = D; g.K = v.Kp; g.pos = v.pos; g.G = G; g.L = L;
+        HG_HIP(gemm(c, EPI_PATCH_F32, g, s));
+        HG_HIP(launch_cls_rows(x, v.cls, v.pos, Bc, L, D, s));
+        HG_HIP(launch_layernorm_f32(x, v.lnpre_w, v.lnpre_b, x, M, D, s));
+        float* tr = trace ? trace + (size_t)b0 * D : nullptr;
+        const int tstride = B * D;
+        if (tr) HG_HIP(launch_copy_rows(x, tr, Bc, L, D, s));
+        AdapterCall ac;
+        ac.enabled = variant_c;
+        ac.priors = priors ? priors + (size_t)b0 * N * 64 : nullptr;
+        ac.mask = mask ? mask + (size_t)b0 * N : nullptr;
+        ac.N = N;
+        rc = run_blocks(c, v.blocks, Bc, L, D, v.heads, false, s, tr, tstride, &ac);
+        if (rc) return rc;
+        half_t* h16 = (half_t*)c->head16.p;
+        if (!variant_c) {
+            // ln_post(x[:,0,:]) @ proj   (clipnet/model.py:231-234)
+            HG_HIP(launch_layernorm_f16(x, v.lnpost_w, v.lnpost_b, h16, Bc, D, nullptr, 0, L, s));
+            g = GemmArgs{};
+            g.A = h16; g.lda = D; g.W = v.w_projT; g.out = out + (size_t)b0 * E; g.ldc = E; g.M = Bc; g.N = E; g.K = D;
+            HG_HIP(gemm(c, EPI_BIAS_F32, g, s));
+        } else {
+            // ln_post + proj on all tokens, split into (global, local NCHW)  (adapter...:501-506)
+            HG_HIP(launch_layernorm_f16(x, v.lnpost_w, v.lnpost_b, h16, M, D, nullptr, 0, 1, s));
+            g = GemmArgs{};
+            g.A = h16; g.lda = D; g.W = v.w_projT; g.out = c->tok32.p; g.ldc = E; g.M = M; g.N = E; g.K = D;
+            HG_HIP(gemm(c, EPI_BIAS_F32, g, s));
+            HG_HIP(launch_split_global_local((const float*)c->tok32.p, out + (size_t)b0 * E,
+                                             out_local + (size_t)b0 * E * G, Bc, L, E, s));
+        }
+    }
+    return HG_OK;
+}
+
+int hg_encode_image(hg_ctx* c, const float* x_nchw, int B, float* out, void* stream) {
+    return encode_image_impl(c, x_nchw, nullptr, nullptr, B, 0, out, nullptr, nullptr, false, (hipStream_t)stream);
+}
+int hg_encode_image_trace(hg_ctx* c, const float* x_nchw, int B, float* out, float* trace, void* stream) {
+    return encode_image_impl(c, x_nchw, nullptr, nullptr, B, 0, out, nullptr, trace, false, (hipStream_t)stream);
+}
+int hg_encode_image_prior(hg_ctx* c, const float* x_nchw, const float* priors, const uint8_t* mask, int B, int N,
+                          float* out_global, float* out_local_nchw, void* stream) {
+    return encode_image_impl(c, x_nchw, priors, mask, B, priors ? N : 0, out_global, out_local_nchw, nullptr, true,
+                             (hipStream_t)stream);
+}
+
+// ---- text tower -------------------------------------------------------------------------------------------
+static int text_tail(hg_ctx* c, int Tc, int Leff, const int32_t* eot, float* out, hipStream_t s) {
+    Text& t = c->text;
+    const int D = t.D, E = t.E;
+    int rc = run_blocks(c, t.blocks, Tc, Leff, D, t.heads, true, s, nullptr, 0, nullptr);
+    if (rc) return rc;
+    half_t* h16 = (half_t*)c->head16.p;
+    // ln_final, select the EOT row, @ text_projection (clipnet/model.py:346-350); LN is row-wise so
+    // selecting before normalising is identical
+    HG_HIP(launch_layernorm_f16((const float*)c->x.p, t.lnf_w, t.lnf_b, h16, Tc, D, eot, Leff, 0, s));
+    GemmArgs g{};
+    g.A = h16; g.lda = D; g.W = t.w_projT; g.out = out; g.ldc = E; g.M = Tc; g.N = E; g.K = D;
+    HG_HIP(gemm(c, EPI_BIAS_F32, g, s));
+    return HG_OK;
+}
+
+int hg_encode_text_ids(hg_ctx* c, const int32_t* ids, int T, int L, float* out, int trunc, void* stream) {
+    if (!c) return HG_ERR_INVALID;
+    Text& t = c->text;
+    if (!t.loaded) return fail(c, HG_ERR_NOT_LOADED, "hg_load_text has not been called");
+    if (T < 0 || !ids || !out || L < 1 || L > t.ctx) return fail(c, HG_ERR_INVALID, "bad arguments to encode_text_ids");
+    hipStream_t s = (hipStream_t)stream;
+    HG_HIP(hipSetDevice(c->device));
+    const int Leff = (trunc > 0 && trunc < L) ? trunc : L;
+    for (int t0 = 0; t0 < T; t0 += c->max_chunk_txt) {
+        const int Tc = (T - t0 < c->max_chunk_txt) ? T - t0 : c->max_chunk_txt;
+        int rc = ensure_tower_ws(c, Tc * Leff, t.D);
+        if (!rc) rc = ensure(c, c->head16, rup(Tc, 128) * t.D * 2);
+        if (!rc) rc = ensure(c, c->i32, (size_t)(Tc + 4) * 4);
+        if (rc) return rc;
+        int32_t* eot = (int32_t*)c->i32.p;
+        // EOT position = argmax over the FULL row (clipnet/model.py:350); must lie inside Leff
+        HG_HIP(launch_eot_argmax(ids + (size_t)t0 * L, Tc, L, eot, nullptr, s));
+        HG_HIP(launch_embed_tokens(ids + (size_t)t0 * L, L, t.tok, t.pos, (float*)c->x.p, Tc, Leff, t.D, t.vocab, s));
+        rc = text_tail(c, Tc, Leff, eot, out + (size_t)t0 * t.E, s);
+        if (rc) return rc;
+    }
+    return HG_OK;
+}
+
+int hg_encode_text_embeds(hg_ctx* c, const float* prompts, const int32_t* eot_idx, int R, int L, float* out,
+                          int trunc, void* stream) {
+    if (!c) return HG_ERR_INVALID;
+    Text& t = c->text;
+    if (!t.loaded) return fail(c, HG_ERR_NOT_LOADED, "hg_load_text has not been called");
+    if (R < 0 || !prompts || !eot_idx || !out || L < 1 || L > t.ctx)
+        return fail(c, HG_ERR_INVALID, "bad arguments to encode_text_embeds");
+    hipStream_t s = (hipStream_t)stream;
+    HG_HIP(hipSetDevice(c->device));
+    const int Leff = (trunc > 0 && trunc < L) ? trunc : L;
+    for (int r0 = 0; r0 < R; r0 += c->max_chunk_txt) {
+        const int Rc = (R - r0 < c->max_chunk_txt) ? R - r0 : c->max_chunk_txt;
+        int rc = ensure_tower_ws(c, Rc * Leff, t.D);
+        if (!rc) rc = ensure(c, c->head16, rup(Rc, 128) * t.D * 2);
+        if (rc) return rc;
+        HG_HIP(launch_add_pos(prompts + (size_t)r0 * L * t.D, L, t.pos, (float*)c->x.p, Rc, Leff, t.D, s));
+        rc = text_tail(c, Rc, Leff, eot_idx + r0, out + (size_t)r0 * t.E, s);
+        if (rc) return rc;
+    }
+    return HG_OK;
+}
+
+int hg_token_embedding(hg_ctx* c, const int32_t* ids, int n, float* out, void* stream) {
+    if (!c) return HG_ERR_INVALID;
+    if (!c->text.loaded) return fail(c, HG_ERR_NOT_LOADED, "hg_load_text has not been called");
+    if (n < 0 || !ids || !out) return fail(c, HG_ERR_INVALID, "bad arguments to token_embedding");
+    HG_HIP(hipSetDevice(c->device));
+    HG_HIP(launch_gather_rows(ids, c->text.tok, out, n, c->text.D, c->text.vocab, (hipStream_t)stream));
+    return HG_OK;
+}
+
+// ---- CoOp-VAE ---------------------------------------------------------------------------------------------
+static int generator_rows(hg_ctx* c, Vae& v, const half_t* z16, int R, float* bias, hipStream_t s) {
+    // Generator: relu(z W0^T + b0) W2^T + b2  (main_coop_vae.py:282-296)
+    half_t* g1 = (half_t*)c->fc.p;
+    GemmArgs g{};
+    g.A = z16; g.lda = v.dim; g.W = v.g_w0; g.bias = v.g_b0; g.out = g1; g.ldc = v.gh; g.M = R; g.N = v.gh; g.K = v.dim;
+    HG_HIP(gemm(c, EPI_BIAS_RELU_F16, g, s));
+    g = GemmArgs{};
+    g.A = g1; g.lda = v.gh; g.W = v.g_w2; g.bias = v.g_b2; g.out = bias; g.ldc = v.dim; g.M = R; g.N = v.dim; g.K = v.gh;
+    HG_HIP(gemm(c, EPI_BIAS_F32, g, s));
+    return HG_OK;
+}
+
+int hg_vae_forward(hg_ctx* c, int slot, const float* x, const float* eps, int R, float* mean, float* logvar,
+                   float* z, float* bias, void* stream) {
+    if (!c || slot < 0 || slot >= HG_MAX_SLOTS) return HG_ERR_INVALID;
+    Vae& v = c->vae[slot];
+    if (!v.enc || (bias && !v.gen)) return fail(c, HG_ERR_NOT_LOADED, "hg_load_vae(slot %d) incomplete", slot);
+    if (R < 0 || !x || !eps) return fail(c, HG_ERR_INVALID, "bad arguments to vae_forward");
+    hipStream_t s = (hipStream_t)stream;
+    HG_HIP(hipSetDevice(c->device));
+    const int dim = v.dim;
+    for (int r0 = 0; r0 < R; r0 += c->max_chunk_rows) {
+        const int Rc = (R - r0 < c->max_chunk_rows) ? R - r0 : c->max_chunk_rows;
+        const size_t Rp = rup(Rc, 128);
+        int rc = ensure(c, c->h, Rp * dim * 2);
+        if (!rc) rc = ensure(c, c->att, Rp * dim * 2);
+        if (!rc) rc = ensure(c, c->qkv, Rp * v.eh * 2);
+        if (!rc) rc = ensure(c, c->x, Rp * 2 * dim * 4);
+        if (!rc && bias) rc = ensure(c, c->fc, Rp * v.gh * 2);
+        if (rc) return rc;
+        half_t* x16 = (half_t*)c->h.p;
+        half_t* z16 = (half_t*)c->att.p;
+        half_t* h1 = (half_t*)c->qkv.p;
+        float* ml = (float*)c->x.p;
+        const size_t o = (size_t)r0 * dim;
+        HG_HIP(launch_f32_to_f16(x + o, x16, (size_t)Rc * dim, s));
+        GemmArgs g{};
+        g.A = x16; g.lda = dim; g.W = v.e_w0; g.bias = v.e_b0; g.out = h1; g.ldc = v.eh; g.M = Rc; g.N = v.eh; g.K = dim;
+        HG_HIP(gemm(c, EPI_BIAS_RELU_F16, g, s));
+        g = GemmArgs{};
+        g.A = h1; g.lda = v.eh; g.W = v.e_wml; g.bias = v.e_bml; g.out = ml; g.ldc = 2 * dim; g.M = Rc; g.N = 2 * dim; g.K = v.eh;
+        HG_HIP(gemm(c, EPI_BIAS_F32, g, s));
+        HG_HIP(launch_reparam(ml, eps + o, Rc, dim, mean ? mean + o : nullptr, logvar ? logvar + o : nullptr,
+                              z ? z + o : nullptr, z16, dim, s));
+        if (bias) {
+            rc = generator_rows(c, v, z16, Rc, bias + o, s);
+            if (rc) return rc;
+        }
+    }
+    return HG_OK;
+}
+
+int hg_generator(hg_ctx* c, int slot, const float* z, int R, float* bias, void* stream) {
+    if (!c || slot < 0 || slot >= HG_MAX_SLOTS) return HG_ERR_INVALID;
+    Vae& v = c->vae[slot];
+    if (!v.gen) return fail(c, HG_ERR_NOT_LOADED, "generator of slot %d not loaded", slot);
+    if (R < 0 || !z || !bias) return fail(c, HG_ERR_INVALID, "bad arguments to generator");
+    hipStream_t s = (hipStream_t)stream;
+    HG_HIP(hipSetDevice(c->device));
+    for (int r0 = 0; r0 < R; r0 += c->max_chunk_rows) {
+        const int Rc = (R - r0 < c->max_chunk_rows) ? R - r0 : c->max_chunk_rows;
+        const size_t Rp = rup(Rc, 128);
+        int rc = ensure(c, c->att, Rp * v.dim * 2);
+        if (!rc) rc = ensure(c, c->fc, Rp * v.gh * 2);
+        if (rc) return rc;
+        half_t* z16 = (half_t*)c->att.p;
+        HG_HIP(launch_f32_to_f16(z + (size_t)r0 * v.dim, z16, (size_t)Rc * v.dim, s));
+        rc = generator_rows(c, v, z16, Rc, bias + (size_t)r0 * v.dim, s);
+        if (rc) return rc;
+    }
+    return HG_OK;
+}
+
+int hg_mlp_net(hg_ctx* c, int slot, const float* x, int R, float* out, void* stream) {
+    if (!c || slot < 0 || slot >= HG_MAX_SLOTS) return HG_ERR_INVALID;
+    Mlp& m = c->mlp[slot];
+    if (!m.loaded) return fail(c, HG_ERR_NOT_LOADED, "mlp_net slot %d not loaded", slot);
+    if (R < 0 || !x || !out) return fail(c, HG_ERR_INVALID, "bad arguments to mlp_net");
+    hipStream_t s = (hipStream_t)stream;
+    HG_HIP(hipSetDevice(c->device));
+    for (int r0 = 0; r0 < R; r0 += c->max_chunk_rows) {
+        const int Rc = (R - r0 < c->max_chunk_rows) ? R - r0 : c->max_chunk_rows;
+        const size_t Rp = rup(Rc, 128);
+        int rc = ensure(c, c->h, Rp * m.in * 2);
+        if (!rc) rc = ensure(c, c->att, Rp * m.hid * 2);
+        if (!rc) rc = ensure(c, c->qkv, Rp * m.hid * 2);
+        if (rc) return rc;
+        half_t* x16 = (half_t*)c->h.p;
+        half_t* a1 = (half_t*)c->att.p;
+        half_t* a2 = (half_t*)c->qkv.p;
+        HG_HIP(launch_f32_to_f16(x + (size_t)r0 * m.in, x16, (size_t)Rc * m.in, s));
+        GemmArgs g{};
+        g.A = x16; g.lda = m.in; g.W = m.w0; g.bias = m.b0; g.out = a1; g.ldc = m.hid; g.M = Rc; g.N = m.hid; g.K = m.in;
+        HG_HIP(gemm(c, EPI_BIAS_RELU_F16, g, s));
+        g = GemmArgs{};
+        g.A = a1; g.lda = m.hid; g.W = m.w2; g.bias = m.b2; g.out = a2; g.ldc = m.hid; g.M = Rc; g.N = m.hid; g.K = m.hid;
+        HG_HIP(gemm(c, EPI_BIAS_RELU_F16, g, s));
+        g = GemmArgs{};
+        g.A = a2; g.lda = m.hid; g.W = m.w4; g.bias = m.b4; g.out = out + (size_t)r0 * m.out; g.ldc = m.out; g.M = Rc; g.N = m.out; g.K = m.hid;
+        HG_HIP(gemm(c, EPI_BIAS_F32, g, s));
+    }
+    return HG_OK;
+}
+
+int hg_assemble_prompts(hg_ctx* c, const float* prefix, const float* suffix, const float* ctx, const float* bias,
+                        const int32_t* target, int R, int C, int L, int n_ctx, int D, float* prompts, void* stream) {
+    if (!c) return HG_ERR_INVALID;
+    if (!prefix || !suffix || !ctx || !bias || !target || !prompts || R < 0 || C <= 0)
+        return fail(c, HG_ERR_INVALID, "bad arguments to assemble_prompts");
+    HG_HIP(hipSetDevice(c->device));
+    HG_HIP(launch_assemble_prompts(prefix, suffix, ctx, bias, target, R, C, L, n_ctx, D, prompts, (hipStream_t)stream));
+    return HG_OK;
+}
+
+int hg_l2_normalize(hg_ctx* c, const float* x, int R, int D, float* out, void* stream) {
+    if (!c) return HG_ERR_INVALID;
+    if (!x || !out || R < 0 || D <= 0) return fail(c, HG_ERR_INVALID, "bad arguments to l2_normalize");
+    HG_HIP(hipSetDevice(c->device));
+    HG_HIP(launch_l2_normalize(x, out, R, D, (hipStream_t)stream));
+    return HG_OK;
+}
+
+int hg_vae_loss(hg_ctx* c, const float* recon, const float* x, const float* mean, const float* logvar, int R,
+                int D, float* loss, void* stream) {
+    if (!c) return HG_ERR_INVALID;
+    if (!recon || !x || !mean || !logvar || !loss || R <= 0) return fail(c, HG_ERR_INVALID, "bad arguments to vae_loss");
+    HG_HIP(hipSetDevice(c->device));
+    HG_HIP(launch_vae_loss(recon, x, mean, logvar, R, D, loss, (hipStream_t)stream));
+    return HG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,429 @@
+// Row / elementwise kernels (HBM-bound): LayerNorm, im2col, token embedding gather, prompt assembly,
+// reparameterisation, L2 normalisation, layout permutations, dtype conversion.  One wave per row
+// where a row reduction is needed; 16-byte accesses per lane.
+#include "hg_kernels.h"
+
+namespace hg {
+
+static constexpr int LN_MAXC = 4;   // float4 chunks per lane -> D <= 1024
+
+// ---- LayerNorm (clipnet/model.py:153-159: fp32 statistics, eps 1e-5, biased variance) ----------
+template <typename OutT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, OutT* __restrict__ out, int M,
+                                                        int D, const int32_t* __restrict__ gather, int rows_per_seq,
+                                                        int in_row_mul) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    size_t in_row;
+    if (gather) {
+        int gidx = gather[r];
+        gidx = gidx < 0 ? 0 : (gidx >= rows_per_seq ? rows_per_seq - 1 : gidx);   // caller error guard
+        in_row = (size_t)r * rows_per_seq + gidx;
+    }
+    else in_row = (size_t)r * in_row_mul;
+    const f32x4* xp = reinterpret_cast<const f32x4*>(x + in_row * D);
+    const int nc = D >> 2;
+    f32x4 v[LN_MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nc) {
+            v[i] = xp[c];
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nc) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
+    const f32x4* wp = reinterpret_cast<const f32x4*>(w);
+    const f32x4* bp = reinterpret_cast<const f32x4*>(b);
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nc) {
+            const f32x4 g = wp[c], be = bp[c];
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + be[e];
+            if constexpr (sizeof(OutT) == 2) {
+                half4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = (half_t)y[e];
+                reinterpret_cast<half4*>(out + (size_t)r * D)[c] = h;
+            } else {
+                reinterpret_cast<f32x4*>(out + (size_t)r * D)[c] = y;
+            }
+        }
+    }
+}
+
+hipError_t launch_layernorm_f16(const float* x, const float* w, const float* b, half_t* out, int M, int D,
+                                const int32_t* gather, int rows_per_seq, int in_row_mul, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    if (D % 4 || D > 256 * LN_MAXC) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_kernel<half_t>, dim3((M + 3) / 4), dim3(256), 0, s, x, w, b, out, M, D, gather,
+                       rows_per_seq, in_row_mul);
+    return hipGetLastError();
+}
+hipError_t launch_layernorm_f32(const float* x, const float* w, const float* b, float* out, int M, int D,
+                                hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    if (D % 4 || D > 256 * LN_MAXC) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_kernel<float>, dim3((M + 3) / 4), dim3(256), 0, s, x, w, b, out, M, D,
+                       (const int32_t*)nullptr, 0, 1);
+    return hipGetLastError();
+}
+
+// ---- im2col: patch matrix of the stride-p conv (clipnet/model.py:220-222) -------------------------
+// thread -> 8 consecutive pixels of one image row segment inside a patch (32 B read, 16 B write)
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, half_t* __restrict__ out, int B,
+                                                     int R, int p) {
+    const int g = R / p, pk = p / 8;
+    const size_t total = (size_t)B * 3 * R * (R / 8);
+    const int K = 3 * p * p;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int xs = (int)(i % (R / 8));          // 8-pixel segment along x
+        size_t rest = i / (R / 8);
+        const int y = (int)(rest % R);
+        rest /= R;
+        const int c = (int)(rest % 3);
+        const int b = (int)(rest / 3);
+        const f32x4* src = reinterpret_cast<const f32x4*>(x + (((size_t)b * 3 + c) * R + y) * R + xs * 8);
+        const f32x4 a = src[0], d = src[1];
+        const int gy = y / p, ky = y - gy * p, gx = xs / pk, kx = (xs - gx * pk) * 8;
+        half8 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h[e] = (half_t)a[e];
+            h[4 + e] = (half_t)d[e];
+        }
+        *reinterpret_cast<half8*>(out + ((size_t)b * g * g + gy * g + gx) * K + c * p * p + ky * p + kx) = h;
+    }
+}
+hipError_t launch_im2col(const float* x, half_t* out, int B, int R, int p, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (p % 8 || R % p) return hipErrorInvalidValue;
+    const size_t total = (size_t)B * 3 * R * (R / 8);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid), dim3(256), 0, s, x, out, B, R, p);
+    return hipGetLastError();
+}
+
+__global__ void cls_rows_kernel(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos,
+                                int B, int L, int D) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * D) return;
+    const int b = i / D, d = i - b * D;
+    x[(size_t)b * L * D + d] = cls[d] + pos[d];
+}
+hipError_t launch_cls_rows(float* x, const float* cls, const float* pos, int B, int L, int D, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(cls_rows_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, x, cls, pos, B, L, D);
+    return hipGetLastError();
+}
+
+// ---- text embedding: x = token_embedding[ids] + positional (clipnet/model.py:340-342) ------------
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const int32_t* __restrict__ ids, int ld_ids,
+                                                           const float* __restrict__ table,
+                                                           const float* __restrict__ pos, float* __restrict__ x,
+                                                           int T, int L, int D, int vocab) {
+    const int nc = D >> 2;
+    const size_t total = (size_t)T * L * nc;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % nc);
+        const size_t r = i / nc;
+        const int t = (int)(r / L), l = (int)(r - (size_t)t * L);
+        int id = ids[(size_t)t * ld_ids + l];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        const f32x4 e = reinterpret_cast<const f32x4*>(table + (size_t)id * D)[c];
+        const f32x4 pe = reinterpret_cast<const f32x4*>(pos + (size_t)l * D)[c];
+        reinterpret_cast<f32x4*>(x + r * D)[c] = e + pe;
+    }
+}
+hipError_t launch_embed_tokens(const int32_t* ids, int ld_ids, const float* table, const float* pos, float* x,
+                               int T, int L, int D, int vocab, hipStream_t s) {
+    if (T <= 0) return hipSuccess;
+    const size_t total = (size_t)T * L * (D / 4);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3(grid), dim3(256), 0, s, ids, ld_ids, table, pos, x, T, L, D, vocab);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void add_pos_kernel(const float* __restrict__ prompts, int Lfull,
+                                                      const float* __restrict__ pos, float* __restrict__ x, int R,
+                                                      int L, int D) {
+    const int nc = D >> 2;
+    const size_t total = (size_t)R * L * nc;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % nc);
+        const size_t r = i / nc;
+        const int t = (int)(r / L), l = (int)(r - (size_t)t * L);
+        const f32x4 e = reinterpret_cast<const f32x4*>(prompts + ((size_t)t * Lfull + l) * D)[c];
+        const f32x4 pe = reinterpret_cast<const f32x4*>(pos + (size_t)l * D)[c];
+        reinterpret_cast<f32x4*>(x + r * D)[c] = e + pe;
+    }
+}
+hipError_t launch_add_pos(const float* prompts, int Lfull, const float* pos, float* x, int R, int L, int D,
+                          hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    const size_t total = (size_t)R * L * (D / 4);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(add_pos_kernel, dim3(grid), dim3(256), 0, s, prompts, Lfull, pos, x, R, L, D);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const int32_t* __restrict__ ids,
+                                                          const float* __restrict__ table, float* __restrict__ out,
+                                                          int n, int D, int vocab) {
+    const int nc = D >> 2;
+    const size_t total = (size_t)n * nc;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % nc);
+        const size_t r = i / nc;
+        int id = ids[r];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        reinterpret_cast<f32x4*>(out + r * D)[c] = reinterpret_cast<const f32x4*>(table + (size_t)id * D)[c];
+    }
+}
+hipError_t launch_gather_rows(const int32_t* ids, const float* table, float* out, int n, int D, int vocab,
+                              hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const size_t total = (size_t)n * (D / 4);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, s, ids, table, out, n, D, vocab);
+    return hipGetLastError();
+}
+
+// ---- EOT index = argmax over the row (first occurrence of the maximum, like torch.argmax;
+// clipnet/model.py:350) and the batch maximum of those indices (for causal truncation) -------------
+__global__ __launch_bounds__(64) void eot_argmax_kernel(const int32_t* __restrict__ ids, int T, int L,
+                                                        int32_t* __restrict__ eot, int32_t* __restrict__ max_eot) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    int best = INT32_MIN, bi = 0x7fffffff;
+    for (int l = lane; l < L; l += 64) {
+        const int v = ids[(size_t)t * L + l];
+        if (v > best) { best = v; bi = l; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int ov = __shfl_xor(best, o, 64), oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        eot[t] = bi;
+        if (max_eot) atomicMax(max_eot, bi);
+    }
+}
+hipError_t launch_eot_argmax(const int32_t* ids, int T, int L, int32_t* eot, int32_t* max_eot, hipStream_t s) {
+    if (T <= 0) return hipSuccess;
+    hipLaunchKernelGGL(eot_argmax_kernel, dim3(T), dim3(64), 0, s, ids, T, L, eot, max_eot);
+    return hipGetLastError();
+}
+
+// ---- dtype conversion / transposition (weight loading) ------------------------------------------------
+__global__ void f32_to_f16_kernel(const float* __restrict__ in, half_t* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = (half_t)in[i];
+}
+__global__ void f16_to_f32_kernel(const half_t* __restrict__ in, float* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = (float)in[i];
+}
+hipError_t launch_f32_to_f16(const float* in, half_t* out, size_t n, hipStream_t s) {
+    if (!n) return hipSuccess;
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(f32_to_f16_kernel, dim3(grid), dim3(256), 0, s, in, out, n);
+    return hipGetLastError();
+}
+hipError_t launch_f16_to_f32(const half_t* in, float* out, size_t n, hipStream_t s) {
+    if (!n) return hipSuccess;
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(f16_to_f32_kernel, dim3(grid), dim3(256), 0, s, in, out, n);
+    return hipGetLastError();
+}
+__global__ void transpose_to_f16_kernel(const void* __restrict__ in, int in_dtype, half_t* __restrict__ out,
+                                        int rows, int cols) {
+    const size_t n = (size_t)rows * cols;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i / rows), r = (int)(i - (size_t)c * rows);   // out[c][r]
+        const size_t src = (size_t)r * cols + c;
+        out[i] = in_dtype == 0 ? (half_t) reinterpret_cast<const float*>(in)[src]
+                               : reinterpret_cast<const half_t*>(in)[src];
+    }
+}
+hipError_t launch_transpose_to_f16(const void* in, int in_dtype, half_t* out, int rows, int cols, hipStream_t s) {
+    const size_t n = (size_t)rows * cols;
+    if (!n) return hipSuccess;
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(transpose_to_f16_kernel, dim3(grid), dim3(256), 0, s, in, in_dtype, out, rows, cols);
+    return hipGetLastError();
+}
+
+// ---- x / ||x||_2 per row (main_coop_vae.py:438,466) ----------------------------------------------
+__global__ __launch_bounds__(256) void l2_normalize_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                           int R, int D) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    float q = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const float v = x[(size_t)r * D + d];
+        q += v * v;
+    }
+    const float inv = 1.0f / sqrtf(wave_sum(q));
+    for (int d = lane; d < D; d += 64) out[(size_t)r * D + d] = x[(size_t)r * D + d] * inv;
+}
+hipError_t launch_l2_normalize(const float* x, float* out, int R, int D, hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(l2_normalize_kernel, dim3((R + 3) / 4), dim3(256), 0, s, x, out, R, D);
+    return hipGetLastError();
+}
+
+// ---- PromptLearner_*.forward (main_coop_vae.py:119-128) -------------------------------------------
+__global__ __launch_bounds__(256) void assemble_prompts_kernel(const float* __restrict__ prefix,
+                                                               const float* __restrict__ suffix,
+                                                               const float* __restrict__ ctx,
+                                                               const float* __restrict__ bias,
+                                                               const int32_t* __restrict__ target, int R, int C, int L,
+                                                               int n_ctx, int D, float* __restrict__ prompts) {
+    const int nc = D >> 2;
+    const size_t total = (size_t)R * L * nc;
+    const int ls = L - 1 - n_ctx;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % nc);
+        const size_t rl = i / nc;
+        const int r = (int)(rl / L), l = (int)(rl - (size_t)r * L);
+        int t = target[r];
+        t = t < 0 ? 0 : (t >= C ? C - 1 : t);
+        f32x4 v;
+        if (l == 0) v = reinterpret_cast<const f32x4*>(prefix + (size_t)t * D)[c];
+        else if (l <= n_ctx)
+            v = reinterpret_cast<const f32x4*>(ctx + (size_t)(l - 1) * D)[c] +
+                reinterpret_cast<const f32x4*>(bias + (size_t)r * D)[c];
+        else v = reinterpret_cast<const f32x4*>(suffix + ((size_t)t * ls + (l - 1 - n_ctx)) * D)[c];
+        reinterpret_cast<f32x4*>(prompts + rl * D)[c] = v;
+    }
+}
+hipError_t launch_assemble_prompts(const float* prefix, const float* suffix, const float* ctx, const float* bias,
+                                   const int32_t* target, int R, int C, int L, int n_ctx, int D, float* prompts,
+                                   hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    if (D % 4 || n_ctx < 0 || n_ctx >= L) return hipErrorInvalidValue;
+    const size_t total = (size_t)R * L * (D / 4);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(assemble_prompts_kernel, dim3(grid), dim3(256), 0, s, prefix, suffix, ctx, bias, target, R, C,
+                       L, n_ctx, D, prompts);
+    return hipGetLastError();
+}
+
+// ---- reparameterise (main_coop_vae.py:445-447): ml = [mean | logvar] -------------------------------
+__global__ __launch_bounds__(256) void reparam_kernel(const float* __restrict__ ml, const float* __restrict__ eps,
+                                                      int R, int D, float* __restrict__ mean,
+                                                      float* __restrict__ logvar, float* __restrict__ z,
+                                                      half_t* __restrict__ z16, int ld16) {
+    const size_t total = (size_t)R * D;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / D;
+        const int d = (int)(i - r * D);
+        const float m = ml[r * 2 * D + d], lv = ml[r * 2 * D + D + d];
+        const float zz = expf(0.5f * lv) * eps[i] + m;
+        if (mean) mean[i] = m;
+        if (logvar) logvar[i] = lv;
+        if (z) z[i] = zz;
+        z16[r * ld16 + d] = (half_t)zz;
+    }
+}
+hipError_t launch_reparam(const float* ml, const float* eps, int R, int D, float* mean, float* logvar, float* z,
+                          half_t* z16, int ld16, hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    const size_t total = (size_t)R * D;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(reparam_kernel, dim3(grid), dim3(256), 0, s, ml, eps, R, D, mean, logvar, z, z16, ld16);
+    return hipGetLastError();
+}
+
+// ---- vae_loss forward (main_coop_vae.py:300-303) ---------------------------------------------------
+__global__ __launch_bounds__(256) void vae_loss_kernel(const float* __restrict__ recon, const float* __restrict__ x,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ logvar, int R, int D,
+                                                       float* __restrict__ loss) {
+    __shared__ float part[4];
+    const size_t total = (size_t)R * D;
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const float d = recon[i] - x[i];
+        const float m = mean[i], lv = logvar[i];
+        acc += d * d - 0.5f * (1.0f + lv - m * m - expf(lv));
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (part[0] + part[1] + part[2] + part[3]) / (float)R);
+}
+hipError_t launch_vae_loss(const float* recon, const float* x, const float* mean, const float* logvar, int R,
+                           int D, float* loss, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), s);
+    if (e != hipSuccess || R <= 0) return e;
+    const size_t total = (size_t)R * D;
+    const int grid = (int)((total + 255) / 256 < 256 ? (total + 255) / 256 : 256);
+    hipLaunchKernelGGL(vae_loss_kernel, dim3(grid), dim3(256), 0, s, recon, x, mean, logvar, R, D, loss);
+    return hipGetLastError();
+}
+
+// ---- variant C output split (CLIP_models_adapter_prior2.py:506): tokens [B*L,E] ->
+//      global [B,E] = token 0; local [B,E,g,g] = tokens 1.. permuted to NCHW --------------------------
+__global__ __launch_bounds__(256) void split_global_local_kernel(const float* __restrict__ tok,
+                                                                 float* __restrict__ glob,
+                                                                 float* __restrict__ local, int B, int L, int E) {
+    // block = one image x 32 channels; stage [G, 32] through LDS so both sides are coalesced
+    __shared__ float tile[32][33];
+    const int G = L - 1;
+    const int b = blockIdx.y, e0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    if (ty == 0 && glob) glob[(size_t)b * E + e0 + tx] = tok[((size_t)b * L) * E + e0 + tx];
+    for (int t0 = 0; t0 < G; t0 += 32) {
+        for (int r = ty; r < 32; r += 8) {
+            const int t = t0 + r;
+            tile[r][tx] = t < G ? tok[((size_t)b * L + 1 + t) * E + e0 + tx] : 0.f;
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {
+            const int t = t0 + tx;
+            if (t < G) local[((size_t)b * E + e0 + r) * G + t] = tile[tx][r];
+        }
+        __syncthreads();
+    }
+}
+hipError_t launch_split_global_local(const float* tok, float* glob, float* local, int B, int L, int E,
+                                     hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (E % 32) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(split_global_local_kernel, dim3(E / 32, B), dim3(256), 0, s, tok, glob, local, B, L, E);
+    return hipGetLastError();
+}
+
+__global__ void copy_rows_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int row_stride, int D) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * D) return;
+    const int b = i / D, d = i - b * D;
+    out[i] = x[(size_t)b * row_stride * D + d];
+}
+hipError_t launch_copy_rows(const float* x, float* out, int B, int row_stride, int D, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, x, out, B, row_stride, D);
+    return hipGetLastError();
+}
+
+}  // namespace hg

@@ -1,0 +1,191 @@
+// fp16 MFMA GEMM for gfx950:  D[m][n] = sum_k A[m][k] * W[n][k]   (both operands K-contiguous,
+// i.e. activations [M,K] x nn.Linear weight [N,K]), fp32 accumulate, fused epilogues.
+//
+// Covers K3/K5/K6/K7/K8/K10 of SURVEY.md §2.2 (clipnet/model.py:171-188 linears, main_coop_vae.py
+// :261-296 linears) = 95 % of the hot path's FLOPs.
+//
+// Structure (v1): 128x128x64 tile, 256 threads = 4 waves (2 along M x 2 along N), each wave a 64x64
+// sub-tile as 4x4 v_mfma_f32_16x16x32_f16.  Operands are staged global -> LDS with 16-byte
+// global_load_lds (no VGPR round trip) into two LDS buffers; the LDS image is XOR-swizzled on the
+// SOURCE address (the DMA destination is lane-linear) so the ds_read_b128 fragment reads are
+// bank-conflict free.  The MFMA is issued "swapped" (W rows as the A operand, activation rows as the
+// B operand) so each lane ends up with 4 consecutive output columns of one output row: 8-byte fp16 /
+// 16-byte fp32 epilogue accesses.
+#include "hg_kernels.h"
+
+namespace hg {
+
+static constexpr int BM = 128, BN = 128, BK = 64;
+static constexpr int TILE_BYTES = 128 * BK * 2;          // 16 KiB per operand tile
+static constexpr int STAGE_BYTES = 2 * TILE_BYTES;       // A + W
+static constexpr int GEMM_LDS = 2 * STAGE_BYTES;         // double buffered: 64 KiB
+
+__device__ __forceinline__ float quick_gelu(float v) {
+    // x * sigmoid(1.702 x)
+    return v * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v));
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue(const GemmArgs& p, int m, int n, f32x4 v) {
+    if (m >= p.M) return;
+    if (p.bias) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+        v += b;
+    }
+    if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_BIAS_RELU_F16) {
+        if constexpr (EPI == EPI_BIAS_QGELU_F16) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
+        }
+        if constexpr (EPI == EPI_BIAS_RELU_F16) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+        }
+        half4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = (half_t)v[r];
+        *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(p.out) + (size_t)m * p.ldc + n) = h;
+    } else if constexpr (EPI == EPI_BIAS_RESID_F32) {
+        f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n);
+        *dst = *dst + v;
+    } else if constexpr (EPI == EPI_SCALE_RESID_F32) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(p.pos + n);
+        f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n);
+        *dst = *dst + v * sc;
+    } else if constexpr (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_RELU_F32) {
+        if constexpr (EPI == EPI_BIAS_RELU_F32) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+        }
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v;
+    } else if constexpr (EPI == EPI_PATCH_F32) {
+        const int b = m / p.G, t = m - b * p.G;
+        const f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (size_t)(1 + t) * p.N + n);
+        const size_t orow = (size_t)b * p.L + 1 + t;
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + orow * p.ldc + n) = v + pe;
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_128x128(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+
+    const int ntn = p.N / BN;
+    const int lt = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = lt / ntn, tn = lt - tm * ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- staging addresses: wave w issues DMA pieces 4w..4w+3 of each operand tile; a piece is 8
+    // rows x 128 B; lane l writes LDS (row = l>>3, chunk' = l&7) and must fetch logical chunk
+    // chunk' ^ swz(row), swz(row) = (row>>1)&7.
+    const half_t* a_src[4];
+    const half_t* w_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        int am = m0 + row;
+        am = am < p.M ? am : p.M - 1;
+        a_src[i] = p.A + (size_t)am * p.lda + chunk * 8;
+        w_src[i] = p.W + (size_t)(n0 + row) * p.K + chunk * 8;
+    }
+    auto stage = [&](int buf) {
+        char* base = smem + buf * STAGE_BYTES + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            glds16(a_src[i], base + i * 1024);
+            glds16(w_src[i], base + TILE_BYTES + i * 1024);
+            a_src[i] += BK;
+            w_src[i] += BK;
+        }
+    };
+
+    // ---- fragment read addresses (bytes inside an operand tile); swz is lane-constant because the
+    // 16-row fragment bases are multiples of 16.
+    const int sw = (lane >> 1) & 7;
+    const int frag_row = (lane & 15) * 128;
+    const int cg = lane >> 4;
+    int a_off[2], w_off[2];   // per k-step; + j*16*128 per fragment
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int c = ((ks * 4 + cg) ^ sw) << 4;
+        a_off[ks] = wm * 64 * 128 + frag_row + c;
+        w_off[ks] = TILE_BYTES + wn * 64 * 128 + frag_row + c;
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    stage(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();   // tile kt landed (vmcnt(0)) and everyone is done with the other buffer
+        if (kt + 1 < nk) stage((kt + 1) & 1);
+        const char* st = smem + (kt & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 xf[4], wf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const half8*>(st + a_off[ks] + j * 2048);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const half8*>(st + w_off[ks] + i * 2048);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: acc[i][j][r] = D[m][n], n = n0 + wn*64 + i*16 + 4*(lane>>4) + r,
+    //                                         m = m0 + wm*64 + j*16 + (lane&15)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + 4 * (lane >> 4);
+            epilogue<EPI>(p, m, n, acc[i][j]);
+        }
+    }
+}
+
+template <int EPI>
+static hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_128x128<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
+    hipLaunchKernelGGL(gemm_nt_128x128<EPI>, dim3(grid), dim3(256), GEMM_LDS, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm(int epi, const GemmArgs& a, hipStream_t s) {
+    if (a.M <= 0) return hipSuccess;
+    if (a.N % BN != 0 || a.K % BK != 0 || (a.lda % 8) != 0 || (a.ldc % 4) != 0) return hipErrorInvalidValue;
+    switch (epi) {
+        case EPI_BIAS_F16: return launch_t<EPI_BIAS_F16>(a, s);
+        case EPI_BIAS_QGELU_F16: return launch_t<EPI_BIAS_QGELU_F16>(a, s);
+        case EPI_BIAS_RELU_F16: return launch_t<EPI_BIAS_RELU_F16>(a, s);
+        case EPI_BIAS_RESID_F32: return launch_t<EPI_BIAS_RESID_F32>(a, s);
+        case EPI_BIAS_F32: return launch_t<EPI_BIAS_F32>(a, s);
+        case EPI_PATCH_F32: return launch_t<EPI_PATCH_F32>(a, s);
+        case EPI_BIAS_RELU_F32: return launch_t<EPI_BIAS_RELU_F32>(a, s);
+        case EPI_SCALE_RESID_F32: return launch_t<EPI_SCALE_RESID_F32>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+double gemm_flops(const GemmArgs& a) { return 2.0 * a.M * (double)a.N * a.K; }
+
+}  // namespace hg

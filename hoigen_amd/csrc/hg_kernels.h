@@ -1,0 +1,99 @@
+// Host-callable launchers of the gfx950 kernels (internal; the public ABI is include/hoigen_amd.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hg_common.h"
+
+namespace hg {
+
+// ---- GEMM:  D[m][n] = sum_k A[m][k] * W[n][k]  (fp16 operands, fp32 accumulate) ---------------
+enum Epilogue : int {
+    EPI_BIAS_F16 = 0,        // out fp16 [M,ldc] = acc + bias
+    EPI_BIAS_QGELU_F16 = 1,  // out fp16 = quickgelu(acc + bias)        (clipnet/model.py:162-164)
+    EPI_BIAS_RELU_F16 = 2,   // out fp16 = relu(acc + bias)
+    EPI_BIAS_RESID_F32 = 3,  // out fp32 += acc + bias   (residual stream, in place)
+    EPI_BIAS_F32 = 4,        // out fp32 = acc + bias (bias may be null)
+    EPI_PATCH_F32 = 5,       // patch embedding: row m=(b,t) -> out row b*L+1+t, + pos[1+t]
+    EPI_BIAS_RELU_F32 = 6,   // out fp32 = relu(acc + bias)
+    EPI_SCALE_RESID_F32 = 7  // out fp32 += (acc + bias) * pos[n]   (adapter up_proj * scale, residual)
+};
+
+struct GemmArgs {
+    const half_t* A;   // [M, lda] (K contiguous)
+    const half_t* W;   // [N, K]
+    const float* bias; // [N] or nullptr
+    void* out;
+    const float* pos;  // EPI_PATCH: positional embedding [L, N]
+    int lda, ldc;
+    int M, N, K;
+    int G, L;          // EPI_PATCH: patches per image, tokens per image
+};
+
+// Requirements: N % 128 == 0, K % 64 == 0, A readable for rows < M, 16-byte aligned rows.
+hipError_t launch_gemm(int epi, const GemmArgs& a, hipStream_t s);
+double gemm_flops(const GemmArgs& a);
+
+// ---- attention: softmax(Q K^T / sqrt(64) [+causal]) V, head_dim 64 --------------------------
+// qkv fp16 [n_seq*L, 3*D] rows = tokens (q|k|v column blocks, head h = 64h..64h+63);
+// out fp16 [n_seq*L, D].  L <= 224.
+hipError_t launch_attention(const half_t* qkv, half_t* out, int n_seq, int L, int heads, bool causal,
+                            hipStream_t s);
+
+// ---- elementwise / row kernels ---------------------------------------------------------------
+// LayerNorm over rows of fp32 x (eps 1e-5, biased variance; clipnet/model.py:153-159).
+// Input row for output row r:  gather ? r*rows_per_seq + gather[r] : r*in_row_stride_rows.
+hipError_t launch_layernorm_f16(const float* x, const float* w, const float* b, half_t* out, int M, int D,
+                                const int32_t* gather, int rows_per_seq, int in_row_mul, hipStream_t s);
+hipError_t launch_layernorm_f32(const float* x, const float* w, const float* b, float* out, int M, int D,
+                                hipStream_t s);
+// NCHW fp32 crops -> patch matrix fp16 [B*g*g, 3*p*p] (token t = g*row+col, k = c*p*p+ky*p+kx).
+hipError_t launch_im2col(const float* x, half_t* out, int B, int R, int p, hipStream_t s);
+// x[b*L + 0][:] = cls + pos[0]
+hipError_t launch_cls_rows(float* x, const float* cls, const float* pos, int B, int L, int D, hipStream_t s);
+// x[r][:] = table[ids[r/L*ld_ids + r%L]][:] + pos[r%L][:]   (text: token_embedding + positional)
+hipError_t launch_embed_tokens(const int32_t* ids, int ld_ids, const float* table, const float* pos, float* x,
+                               int T, int L, int D, int vocab, hipStream_t s);
+// x[r][:] = prompts[(r/L)*Lfull + r%L][:] + pos[r%L][:]
+hipError_t launch_add_pos(const float* prompts, int Lfull, const float* pos, float* x, int R, int L, int D,
+                          hipStream_t s);
+hipError_t launch_gather_rows(const int32_t* ids, const float* table, float* out, int n, int D, int vocab,
+                              hipStream_t s);
+hipError_t launch_eot_argmax(const int32_t* ids, int T, int L, int32_t* eot, int32_t* max_eot, hipStream_t s);
+hipError_t launch_f32_to_f16(const float* in, half_t* out, size_t n, hipStream_t s);
+hipError_t launch_f16_to_f32(const half_t* in, float* out, size_t n, hipStream_t s);
+// out[c][r] = in[r][c]  (fp32 or fp16 in -> fp16 out), used for `proj` / `text_projection` [in,out]
+hipError_t launch_transpose_to_f16(const void* in, int in_dtype, half_t* out, int rows, int cols, hipStream_t s);
+hipError_t launch_l2_normalize(const float* x, float* out, int R, int D, hipStream_t s);
+hipError_t launch_assemble_prompts(const float* prefix, const float* suffix, const float* ctx, const float* bias,
+                                   const int32_t* target, int R, int C, int L, int n_ctx, int D, float* prompts,
+                                   hipStream_t s);
+// ml [R, 2*D] = mean|logvar  ->  mean, logvar, z fp32 (optional) and z fp16 (GEMM operand)
+hipError_t launch_reparam(const float* ml, const float* eps, int R, int D, float* mean, float* logvar, float* z,
+                          half_t* z16, int ld16, hipStream_t s);
+hipError_t launch_vae_loss(const float* recon, const float* x, const float* mean, const float* logvar, int R,
+                           int D, float* loss, hipStream_t s);
+// tokens [B*L, E] fp32 -> global [B,E] (token 0) and local [B,E,g,g] (tokens 1..), NCHW
+hipError_t launch_split_global_local(const float* tok, float* glob, float* local, int B, int L, int E,
+                                     hipStream_t s);
+hipError_t launch_copy_rows(const float* x, float* out, int B, int row_stride, int D, hipStream_t s);
+
+// ---- adapter (variant C) --------------------------------------------------------------------
+struct AdapterDev {      // device pointers, all fp32 except the two MFMA operands
+    const half_t* down_w;   // [d, D] fp16
+    const float* down_b;    // [d]
+    const half_t* up_w;     // [D, d] fp16
+    const float* up_b;      // [D]
+    const float* scale;     // [D]
+    // decoder layers [0] = mhsa_layers.0 (prior memory), [1] = mhsa (self memory); fp32, weights
+    // transposed to [in][out]:  0 WqT 1 WkT 2 WvT 3 bq 4 bk 5 bv 6 WoT 7 bo 8 {norm2.w,norm2.b,norm3.w,
+    // norm3.b} 9 W1T [d][2d] 10 b1 11 {W2T [2d][d], b2}
+    const float* dl[2][12];
+};
+// down32 [M,128] fp32 (cols 0..63 = relu(down_proj(x))) -> out16 [M,64] fp16 (decoder layer output);
+// kv: scratch [B*Nmem, 2, 64] fp32 with Nmem = N (prior given) or L (prior == nullptr).
+hipError_t launch_adapter_decoder(const float* down32, const AdapterDev& ad, const float* priors,
+                                  const uint8_t* mask, int B, int L, int N, float* kv, half_t* out16,
+                                  hipStream_t s);
+
+}  // namespace hg

@@ -116,7 +116,7 @@ def clip_state_dict(cfg: dict = VIT_B16, seed: int = 0, ln_jitter: float = 0.1) 
 
     put("positional_embedding", (cfg["context_length"], tw), 0.01)
     put("text_projection", (tw, cfg["embed_dim"]), tw ** -0.5)
-    sd["logit_scale"] = np.float32(np.log(1 / 0.07)).reshape(())
+    sd["logit_scale"] = np.array(np.log(1 / 0.07), dtype=np.float32)
     for i in range(cfg["transformer_layers"]):
         _block(sd, f"transformer.resblocks.{i}.", tw, cfg["transformer_layers"], seed, ln_jitter)
     put("token_embedding.weight", (cfg["vocab_size"], tw), 0.02)
@@ -240,3 +240,14 @@ def priors(batch: int, n: int = 14, dim: int = 64, n_pad: int = 4, seed: int = 9
         if k:
             mask[b, n - k:] = True
     return p, mask
+
+
+def to_torch(sd_np, device=None):
+    """numpy state dict -> OrderedDict of torch tensors (optionally on ``device``)."""
+    import torch
+
+    out = OrderedDict()
+    for k, v in sd_np.items():
+        t = torch.from_numpy(np.array(v, copy=True))
+        out[k] = t.to(device) if device is not None else t
+    return out

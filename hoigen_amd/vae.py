@@ -1,0 +1,295 @@
+"""CoOp-VAE feature generator façade: the reference's classes with the same names, constructor
+arguments, ``state_dict`` keys and call signatures, running on the HIP kernels.
+
+Reference: /root/reference/main_coop_vae.py — ``TextEncoder`` :45-63, ``PromptLearner_{hoi,h,o}``
+:66-258, ``Encoder`` :261-279, ``Generator`` :282-296, ``vae_loss`` :300-303; ``mlp_net``
+/root/reference/finetune_ship.py:302-314 (twin main_tip_finetune.py:313-324).
+
+Inference only (no autograd through the kernels); tensors must live on a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch import nn
+
+from . import _lib
+from . import clip as _clip
+from .model import CLIP, Linear, _Ctx, _require_cuda, _sig, _stream_ptr
+
+
+def weights_init(m):
+    """main_coop_vae.py:32-39."""
+    if isinstance(m, Linear):
+        m.weight.data.normal_(0.0, 0.02)
+        m.bias.data.fill_(0)
+
+
+class _Seq(nn.Module):
+    """Numbered children like nn.Sequential (keys ``net.0.weight`` ...); ReLUs carry no parameters."""
+
+    def __init__(self, layers: Sequence[Tuple[int, nn.Module]]):
+        super().__init__()
+        for i, m in layers:
+            self.add_module(str(i), m)
+
+    def __getitem__(self, i: int) -> nn.Module:
+        return getattr(self, str(i))
+
+
+def _f32(x: torch.Tensor) -> torch.Tensor:
+    return x.detach().to(torch.float32).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+class Encoder(nn.Module):
+    """main_coop_vae.py:261-279: Linear(512,2048)+ReLU -> mean, log_var Linear(2048,512)."""
+
+    def __init__(self, dim: int = 512, hidden: int = 2048):
+        super().__init__()
+        self.dim, self.hidden = dim, hidden
+        self.net = _Seq([(0, Linear(dim, hidden))])
+        self.mean = Linear(hidden, dim)
+        self.log_var = Linear(hidden, dim)
+        self.apply(weights_init)
+        self._ctx = _Ctx()
+        self._sig = None
+
+    def _weights(self, w: _lib.hg_vae_weights):
+        t = _lib.tensor
+        w.dim, w.enc_hidden = self.dim, self.hidden
+        w.enc_w0, w.enc_b0 = t(self.net[0].weight), t(self.net[0].bias)
+        w.enc_mean_w, w.enc_mean_b = t(self.mean.weight), t(self.mean.bias)
+        w.enc_logvar_w, w.enc_logvar_b = t(self.log_var.weight), t(self.log_var.bias)
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor):
+        _require_cuda(x, "Encoder input")
+        h = self._ctx.get(x.device)
+        sig = _sig(self.parameters())
+        if sig != self._sig:
+            w = _lib.hg_vae_weights()
+            self._weights(w)
+            self._ctx.check(_lib.lib().hg_load_vae(h, 0, C.byref(w)), "hg_load_vae")
+            self._sig = sig
+        xf = _f32(x)
+        R = xf.shape[0]
+        mean, logvar = torch.empty_like(xf), torch.empty_like(xf)
+        zeros = torch.zeros_like(xf)          # eps = 0: z is not requested
+        self._ctx.check(_lib.lib().hg_vae_forward(h, 0, xf.data_ptr(), zeros.data_ptr(), R, mean.data_ptr(),
+                                                  logvar.data_ptr(), None, None, _stream_ptr(x.device)),
+                        "hg_vae_forward")
+        return mean, logvar
+
+
+class Generator(nn.Module):
+    """main_coop_vae.py:282-296: Linear(512,4096) -> ReLU -> Linear(4096,512)."""
+
+    def __init__(self, dim: int = 512, hidden: int = 4096):
+        super().__init__()
+        self.dim, self.hidden = dim, hidden
+        self.net = _Seq([(0, Linear(dim, hidden)), (2, Linear(hidden, dim))])
+        self.apply(weights_init)
+        self._ctx = _Ctx()
+        self._sig = None
+
+    def _weights(self, w: _lib.hg_vae_weights):
+        t = _lib.tensor
+        w.dim, w.gen_hidden = self.dim, self.hidden
+        w.gen_w0, w.gen_b0 = t(self.net[0].weight), t(self.net[0].bias)
+        w.gen_w2, w.gen_b2 = t(self.net[2].weight), t(self.net[2].bias)
+
+    @torch.no_grad()
+    def forward(self, z: torch.Tensor) -> torch.Tensor:
+        _require_cuda(z, "Generator input")
+        h = self._ctx.get(z.device)
+        sig = _sig(self.parameters())
+        if sig != self._sig:
+            w = _lib.hg_vae_weights()
+            self._weights(w)
+            self._ctx.check(_lib.lib().hg_load_vae(h, 0, C.byref(w)), "hg_load_vae")
+            self._sig = sig
+        zf = _f32(z)
+        out = torch.empty_like(zf)
+        self._ctx.check(_lib.lib().hg_generator(h, 0, zf.data_ptr(), zf.shape[0], out.data_ptr(),
+                                                _stream_ptr(z.device)), "hg_generator")
+        return out
+
+
+class VAE:
+    """Fused Encoder -> reparameterise -> Generator (main_coop_vae.py:444-448) in one native call.
+
+    ``eps`` is an input (the reference draws it with torch.randn at :446); pass ``eps=None`` to draw it
+    with torch on the device.
+    """
+
+    def __init__(self, netE: Encoder, netG: Generator):
+        self.netE, self.netG = netE, netG
+        self._ctx = _Ctx()
+        self._sig = None
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None):
+        _require_cuda(x, "VAE input")
+        h = self._ctx.get(x.device)
+        sig = _sig(list(self.netE.parameters()) + list(self.netG.parameters()))
+        if sig != self._sig:
+            w = _lib.hg_vae_weights()
+            self.netE._weights(w)
+            self.netG._weights(w)
+            self._ctx.check(_lib.lib().hg_load_vae(h, 0, C.byref(w)), "hg_load_vae")
+            self._sig = sig
+        xf = _f32(x)
+        ef = torch.randn_like(xf) if eps is None else _f32(eps)
+        mean, logvar, z, bias = (torch.empty_like(xf) for _ in range(4))
+        self._ctx.check(_lib.lib().hg_vae_forward(h, 0, xf.data_ptr(), ef.data_ptr(), xf.shape[0], mean.data_ptr(),
+                                                  logvar.data_ptr(), z.data_ptr(), bias.data_ptr(),
+                                                  _stream_ptr(x.device)), "hg_vae_forward")
+        return mean, logvar, z, bias
+
+
+class mlp_net(nn.Module):
+    """finetune_ship.py:302-314."""
+
+    def __init__(self, input_dim: int, output_dim: int, hidden_dim: int):
+        super().__init__()
+        self.dims = (input_dim, hidden_dim, output_dim)
+        self.net = _Seq([(0, Linear(input_dim, hidden_dim)), (2, Linear(hidden_dim, hidden_dim)),
+                         (4, Linear(hidden_dim, output_dim))])
+        self._ctx = _Ctx()
+        self._sig = None
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        _require_cuda(x, "mlp_net input")
+        h = self._ctx.get(x.device)
+        sig = _sig(self.parameters())
+        if sig != self._sig:
+            t = _lib.tensor
+            w = _lib.hg_mlp_weights(self.dims[0], self.dims[1], self.dims[2], t(self.net[0].weight),
+                                    t(self.net[0].bias), t(self.net[2].weight), t(self.net[2].bias),
+                                    t(self.net[4].weight), t(self.net[4].bias))
+            self._ctx.check(_lib.lib().hg_load_mlp(h, 0, C.byref(w)), "hg_load_mlp")
+            self._sig = sig
+        xf = _f32(x)
+        out = torch.empty(xf.shape[0], self.dims[2], device=x.device, dtype=torch.float32)
+        self._ctx.check(_lib.lib().hg_mlp_net(h, 0, xf.data_ptr(), xf.shape[0], out.data_ptr(), _stream_ptr(x.device)),
+                        "hg_mlp_net")
+        return out
+
+
+# ---------------------------------------------------------------------------------------------
+_util_ctx = _Ctx()
+
+
+@torch.no_grad()
+def l2_normalize(x: torch.Tensor) -> torch.Tensor:
+    """``x / x.norm(dim=-1, keepdim=True)`` (main_coop_vae.py:438,466) on the device."""
+    _require_cuda(x, "input")
+    h = _util_ctx.get(x.device)
+    xf = _f32(x)
+    out = torch.empty_like(xf)
+    _util_ctx.check(_lib.lib().hg_l2_normalize(h, xf.data_ptr(), xf.shape[0], xf.shape[1], out.data_ptr(),
+                                               _stream_ptr(x.device)), "hg_l2_normalize")
+    return out
+
+
+@torch.no_grad()
+def vae_loss(recon_x, x, mean, log_var, target=None) -> torch.Tensor:
+    """Forward value of main_coop_vae.py:300-303 (``target`` is unused there as well)."""
+    _require_cuda(x, "input")
+    h = _util_ctx.get(x.device)
+    a, b, m, lv = _f32(recon_x), _f32(x), _f32(mean), _f32(log_var)
+    loss = torch.empty(1, device=x.device, dtype=torch.float32)
+    _util_ctx.check(_lib.lib().hg_vae_loss(h, a.data_ptr(), b.data_ptr(), m.data_ptr(), lv.data_ptr(), b.shape[0],
+                                           b.shape[1], loss.data_ptr(), _stream_ptr(x.device)), "hg_vae_loss")
+    return loss[0]
+
+
+class TextEncoder(nn.Module):
+    """main_coop_vae.py:45-63 — shares the CLIP model's text tower (no copies)."""
+
+    def __init__(self, clip_model: CLIP):
+        super().__init__()
+        object.__setattr__(self, "_clip", clip_model)
+        self.transformer = clip_model.transformer
+        self.positional_embedding = clip_model.positional_embedding
+        self.ln_final = clip_model.ln_final
+        self.text_projection = clip_model.text_projection
+        self.dtype = clip_model.dtype
+
+    def forward(self, prompts: torch.Tensor, tokenized_prompts: torch.Tensor) -> torch.Tensor:
+        return self._clip.encode_text_embeds(prompts, tokenized_prompts)
+
+
+class _PromptLearner(nn.Module):
+    """PromptLearner_{hoi,h,o} (main_coop_vae.py:66-258): learnable context ``ctx [n_ctx,D]`` shifted by
+    a per-sample ``bias`` between the SOT embedding and the class-name suffix.  The three reference
+    classes differ only in ``n_ctx`` (5 / 4 / 4)."""
+
+    N_CTX = 4
+
+    def __init__(self, classnames: List[str], clip_model: CLIP):
+        super().__init__()
+        n_ctx = self.N_CTX
+        self.dtype = clip_model.dtype
+        ctx_dim = clip_model.ln_final.weight.shape[0]
+        self.n_cls, self.n_ctx = len(classnames), n_ctx
+        dev = clip_model.positional_embedding.device
+        ctx_vectors = torch.empty(n_ctx, ctx_dim, dtype=self.dtype, device=dev)
+        nn.init.normal_(ctx_vectors, std=0.02)
+        self.prompt_prefix = " ".join(["X"] * n_ctx)
+        self.ctx = nn.Parameter(ctx_vectors)
+        self._names_key = None
+        self.get_prefix_suffix_token(classnames, clip_model)
+
+    def get_prefix_suffix_token(self, classnames: List[str], clip_model: CLIP):
+        """main_coop_vae.py:103-117.  The reference re-tokenises every class name on the CPU each
+        training / sampling step (:451, main_tip_finetune.py:783); the result depends only on the class
+        names and the frozen token embedding, so it is cached per class-name list."""
+        key = (tuple(classnames), clip_model.token_embedding.weight.data_ptr(),
+               clip_model.token_embedding.weight._version)
+        if key == self._names_key:
+            return
+        names = [n.replace("_", " ") for n in classnames]
+        self.name_lens = [len(_clip._tokenizer.encode(n)) for n in names]
+        prompts = [self.prompt_prefix + " " + n + "." for n in names]
+        dev = clip_model.positional_embedding.device
+        tokenized = torch.cat([_clip.tokenize(p) for p in prompts]).to(dev)
+        with torch.no_grad():
+            embedding = clip_model.token_embedding(tokenized).type(self.dtype)
+        self.register_buffer("token_prefix", embedding[:, :1, :].contiguous())
+        self.register_buffer("token_suffix", embedding[:, 1 + self.n_ctx:, :].contiguous())
+        self.tokenized_prompts = tokenized
+        self._names_key = key
+
+    @torch.no_grad()
+    def forward(self, bias: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        """main_coop_vae.py:119-128 -> prompts [R, L, D]."""
+        _require_cuda(bias, "bias")
+        h = _util_ctx.get(bias.device)
+        bf = _f32(bias)
+        R, D = bf.shape
+        C_, Ls = self.token_suffix.shape[0], self.token_suffix.shape[1]
+        L = 1 + self.n_ctx + Ls
+        tgt = target.to(device=bias.device, dtype=torch.int32).contiguous()
+        out = torch.empty(R, L, D, device=bias.device, dtype=torch.float32)
+        _util_ctx.check(_lib.lib().hg_assemble_prompts(
+            h, _f32(self.token_prefix).data_ptr(), _f32(self.token_suffix).data_ptr(), _f32(self.ctx).data_ptr(),
+            bf.data_ptr(), tgt.data_ptr(), R, C_, L, self.n_ctx, D, out.data_ptr(), _stream_ptr(bias.device)),
+            "hg_assemble_prompts")
+        return out
+
+
+class PromptLearner_hoi(_PromptLearner):
+    N_CTX = 5      # main_coop_vae.py:70
+
+
+class PromptLearner_h(_PromptLearner):
+    N_CTX = 4      # main_coop_vae.py:135
+
+
+class PromptLearner_o(_PromptLearner):
+    N_CTX = 4      # main_coop_vae.py:200

@@ -188,8 +188,14 @@ int hg_vae_loss(hg_ctx*, const float* recon, const float* x, const float* mean, 
                 int R, int D, float* loss, void* stream);
 
 /* ---- introspection for bench.py (no reference counterpart) --------------------------------- */
-/* Name of the dominant GEMM kernel and FLOPs per launch for the last hg_encode_image call. */
 int hg_workspace_bytes(hg_ctx*, uint64_t* bytes);
+/* Live per-kernel timing: from hg_profile_begin until hg_profile_end every launch of the GEMM kernel
+ * with epilogue class `gemm_class` (0 bias->f16 [QKV], 1 bias+QuickGELU->f16 [c_fc], 3 bias+residual
+ * [out_proj, c_proj], ...; only launches with the same M,N,K as the first one are counted) is
+ * bracketed by a hipEvent pair on its own stream.  hg_profile_end synchronises and returns the mean
+ * duration, the launch count, the algorithmic FLOPs of one launch (2*M*N*K) and {M,N,K}. */
+int hg_profile_begin(hg_ctx*, int gemm_class, int max_launches);
+int hg_profile_end(hg_ctx*, double* avg_ms, int32_t* launches, double* flops_per_launch, int32_t* mnk);
 
 #ifdef __cplusplus
 }

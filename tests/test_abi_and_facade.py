@@ -1,0 +1,124 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol the header declares, the ctypes
+binding lists them all, the façade reproduces the reference's state-dict contract and error behaviour,
+and the product fails loudly without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from hoigen_amd import _lib, clip, synth
+from hoigen_amd.model import build_model
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(REPO, "include", "hoigen_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(hg_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    syms = header_symbols()
+    assert len(syms) >= 20
+    assert os.path.exists(_lib.LIB_PATH), "build the library first: python -c 'import __graft_entry__ as g; g.build()'"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/hoigen_amd.h but not exported"
+    assert sorted(_lib.SIGNATURES) == syms, "ctypes SIGNATURES out of sync with the header"
+    assert b"gfx950" in _lib.lib().hg_version()
+
+
+def test_struct_layouts_match_header_field_counts():
+    src = open(os.path.join(REPO, "include", "hoigen_amd.h")).read()
+    def n_tensor_fields(name):
+        body = dict((n, b) for b, n in re.findall(r"typedef struct \{([^}]*)\} (\w+);", src))[name]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        return sum(len(d.split(",")) for d in re.findall(r"hg_tensor\s+([^;]+);", body))
+    assert n_tensor_fields("hg_block_weights") == 12 == len(_lib.hg_block_weights._fields_)
+    assert n_tensor_fields("hg_decoder_layer_weights") == 12 == len(_lib.hg_decoder_layer_weights._fields_)
+    assert n_tensor_fields("hg_vae_weights") == 10 == len(_lib.hg_vae_weights._fields_) - 3
+    assert ctypes.sizeof(_lib.hg_tensor) == 16
+
+
+def test_state_dict_contract_vitb16():
+    """302 tensors with the reference's keys/shapes/dtypes."""
+    sd = synth.to_torch(synth.clip_state_dict(synth.VIT_B16, 0))
+    sd["input_resolution"] = torch.tensor(224)      # metadata keys are dropped (clipnet/model.py:426-428)
+    sd["context_length"] = torch.tensor(77)
+    sd["vocab_size"] = torch.tensor(49408)
+    m = build_model(sd)
+    got = m.state_dict()
+    assert len(got) == 302
+    want = synth.clip_state_dict(synth.VIT_B16, 0)
+    assert list(sorted(got)) == list(sorted(want))
+    for k, v in want.items():
+        assert tuple(got[k].shape) == tuple(v.shape), k
+    # dtype contract of convert_weights (clipnet/model.py:371-392)
+    assert m.dtype == torch.float16
+    assert got["visual.transformer.resblocks.3.mlp.c_fc.bias"].dtype == torch.float16
+    assert got["visual.proj"].dtype == torch.float16 and got["text_projection"].dtype == torch.float16
+    for k in ("visual.ln_pre.weight", "token_embedding.weight", "positional_embedding",
+              "visual.class_embedding", "visual.positional_embedding", "logit_scale",
+              "transformer.resblocks.0.ln_1.bias"):
+        assert got[k].dtype == torch.float32, k
+    assert not m.training
+    assert m.visual.output_dim == 512 and m.visual.input_resolution == 224
+    assert m.float().dtype == torch.float32
+    mask = m.build_attention_mask()
+    assert mask.shape == (77, 77) and mask[0, 1] == float("-inf") and mask[1, 0] == 0
+
+
+def test_variant_c_contract():
+    sd = synth.to_torch(synth.clip_state_dict(synth.TINY, 10))
+    m = build_model(sd, use_adapter=True, adapter_pos="front")
+    keys = set(m.state_dict())
+    assert "visual.transformer.resblocks.0.adaptermlp.scale" in keys
+    assert "visual.transformer.resblocks.0.adaptermlp.mhsa_layers.0.multihead_attn.in_proj_weight" in keys
+    assert "visual.transformer.resblocks.0.adaptermlp.mhsa.norm1.weight" in keys
+    assert "visual.transformer.resblocks.1.adaptermlp.scale" not in keys       # 'front' = first half
+    assert m.dtype == torch.float32                                            # no convert_weights (adapter...:980)
+    want = set(synth.clip_state_dict(synth.TINY, 10)) | set(synth.adapter_state_dict(synth.TINY, 13, layers=[0]))
+    assert want <= keys
+    # untrained adapter init: scale 1e-9, up_proj zero (adapter...:157,172)
+    a = m.visual.transformer.resblocks[0].adaptermlp
+    assert float(a.scale.max()) == pytest.approx(1e-9) and float(a.up_proj.weight.abs().max()) == 0.0
+    # trainable-parameter selection by name works as in main_tip_finetune.py:955-962
+    names = [n for n, _ in m.named_parameters()]
+    assert any("adaptermlp" in n for n in names) and "visual.proj" in names and "visual.ln_post.weight" in names
+
+
+def test_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    m = build_model(synth.to_torch(synth.clip_state_dict(synth.TINY, 10)))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        m.encode_image(torch.zeros(1, 3, 32, 32))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        m.encode_text(torch.zeros(1, 16, dtype=torch.long))
+    assert _lib.lib().hg_create(0) is None
+
+
+def test_load_error_behaviour(tmp_path):
+    with pytest.raises(RuntimeError, match="not found"):
+        clip.load("no-such-model")                          # clipnet/clip.py:120
+    assert "ViT-B/16" in clip.available_models()
+    # a plain state-dict checkpoint loads through the torch.load branch (clipnet/clip.py:127-131)
+    p = tmp_path / "tiny.pt"
+    torch.save(synth.to_torch(synth.clip_state_dict(synth.TINY, 10)), p)
+    model, preprocess = clip.load(str(p), device="cpu")
+    assert model.dtype == torch.float32 and model.visual.input_resolution == 32
+    from PIL import Image
+    img = Image.new("RGB", (50, 40), (255, 0, 0))
+    x = preprocess(img)
+    assert x.shape == (3, 32, 32) and x.dtype == torch.float32
+    assert x[0].mean().item() == pytest.approx((1 - 0.48145466) / 0.26862954, rel=1e-4)
+
+
+def test_non_vit_checkpoint_rejected():
+    sd = synth.to_torch(synth.clip_state_dict(synth.TINY, 10))
+    del sd["visual.proj"]
+    with pytest.raises(NotImplementedError):
+        build_model(sd)

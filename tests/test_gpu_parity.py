@@ -1,0 +1,316 @@
+"""Parity of the HIP path (through the C ABI) on a real MI355X.
+
+Three kinds of evidence, per SURVEY.md §8c/§8d:
+  * golden fixtures produced by the REFERENCE ITSELF (tests/golden/*.npz) on seeded synthetic weights;
+  * the CPU oracle (oracle/*.py, itself pinned to those fixtures) on other seeded inputs / sizes;
+  * size-independent properties at BASELINE.json's full sizes (batch invariance, determinism).
+
+Tolerance (north_star): relative 1e-3 vs the fp32 reference.  We assert the relative L2 error of the
+whole tensor AND of every row: ||y - ref||_2 / ||ref||_2 <= 1e-3.  Integer artefacts are exact.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from hoigen_amd import clip, synth, vae
+from hoigen_amd.model import build_model
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-3
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def rel_l2(a, b):
+    a = a.detach().float().cpu().numpy().astype(np.float64) if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.isfinite(a).all(), "non-finite values in the HIP output"
+    whole = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+    a2, b2 = a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1])
+    rows = np.linalg.norm(a2 - b2, axis=1) / np.maximum(np.linalg.norm(b2, axis=1), 1e-30)
+    return whole, rows.max()
+
+
+def check(a, b, tol=TOL, what=""):
+    whole, worst = rel_l2(a, b)
+    assert whole <= tol and worst <= tol, f"{what}: rel-L2 {whole:.3e}, worst row {worst:.3e} > {tol}"
+    return whole
+
+
+def ids_from_g0(g0, name, n=None):
+    rows = g0[name]["ids"][:n]
+    ids = np.zeros((len(rows), 77), np.int64)
+    for i, r in enumerate(rows):
+        ids[i, :len(r)] = r
+    return torch.from_numpy(ids)
+
+
+@pytest.fixture(scope="module")
+def g0():
+    return json.load(open(f"{G}/g0_tokens.json"))
+
+
+# ------------------------------------------------------------------------------------------------
+# tiny configuration (golden g1: reference intermediates)
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def g1():
+    return dict(np.load(f"{G}/g1_tiny.npz"))
+
+
+@pytest.fixture(scope="module")
+def tinyA():
+    return build_model(synth.to_torch(synth.clip_state_dict(synth.TINY, 10))).float().to(dev())
+
+
+def test_tiny_image_vs_reference(g1, tinyA):
+    img = torch.from_numpy(synth.crops(3, 32, seed=11)).to(dev())
+    out, trace = tinyA.visual.forward_trace(img)
+    check(trace[0], g1["img_ln_pre"][:, 0, :], what="CLS after ln_pre")
+    for i in range(2):
+        check(trace[1 + i], g1["img_blocks"][i][:, 0, :], what=f"CLS after block {i}")
+    check(out, g1["img_out"], what="encode_image tiny")
+    check(tinyA.encode_image(img), g1["img_out"])
+
+
+def test_tiny_text_vs_reference(g1, tinyA):
+    toks = torch.from_numpy(g1["txt_tokens"])
+    for trunc in (True, False):
+        tinyA.truncate_text = trunc
+        check(tinyA.encode_text(toks.to(dev())), g1["txt_out"], what=f"encode_text tiny trunc={trunc}")
+        check(tinyA.encode_text(toks.int()), g1["txt_out"])                  # int32 ids, host tensor
+    tinyA.truncate_text = True
+
+
+def test_tiny_variant_c_vs_reference(g1):
+    sd = synth.to_torch(synth.clip_state_dict(synth.TINY, 10))
+    sd.update(synth.to_torch(synth.adapter_state_dict(synth.TINY, 13)))
+    m = build_model(sd, use_adapter=True, adapter_pos="all").to(dev())
+    img = torch.from_numpy(synth.crops(3, 32, seed=11)).to(dev())
+    pri, mask = synth.priors(3, n=6, dim=64, n_pad=2, seed=14)
+    prior = (torch.from_numpy(pri).to(dev()), torch.from_numpy(mask).to(dev()))
+    g, l = m.visual(img, prior)
+    assert g.shape == (3, 128) and l.shape == (3, 128, 2, 2)
+    check(g, g1["c_prior_global"], what="C global (prior)")
+    check(l.permute(0, 2, 3, 1), np.transpose(g1["c_prior_local"], (0, 2, 3, 1)), what="C local (prior)")
+    g, l = m.visual(img, None)
+    check(g, g1["c_noprior_global"], what="C global (no prior)")
+    check(l.permute(0, 2, 3, 1), np.transpose(g1["c_noprior_local"], (0, 2, 3, 1)), what="C local (no prior)")
+    check(m.encode_text(torch.from_numpy(g1["txt_tokens"]).int()), g1["c_txt_out"], what="C encode_text")
+    # untrained adapters (reference init) are a no-op: equals the adapter-free output
+    sd0 = synth.to_torch(synth.clip_state_dict(synth.TINY, 10))
+    sd0.update(synth.to_torch(synth.adapter_state_dict(synth.TINY, 13, trained=False)))
+    m0 = build_model(sd0, use_adapter=True).to(dev())
+    g0_, l0_ = m0.visual(img, prior)
+    check(g0_, g1["c_untrained_global"]); check(l0_.permute(0, 2, 3, 1), np.transpose(g1["c_untrained_local"], (0, 2, 3, 1)))
+    # updating only adapter parameters is picked up (hg_update_adapters)
+    with torch.no_grad():
+        for k, v in synth.to_torch(synth.adapter_state_dict(synth.TINY, 13)).items():
+            m0.state_dict()[k].copy_(v)
+    g2_, _ = m0.visual(img, prior)
+    check(g2_, g1["c_prior_global"], what="after adapter update")
+
+
+def test_tiny_vae_chain_vs_reference(g1, tinyA):
+    D = 128
+    d = dev()
+    feats = vae.l2_normalize(tinyA.encode_image(torch.from_numpy(synth.crops(5, 32, seed=16)).to(d)).float())
+    check(feats, g1["vae_feats"], what="normalised crop features")
+    E, Gn = vae.Encoder(D, 256).to(d), vae.Generator(D, 384).to(d)
+    E.load_state_dict(synth.to_torch(synth.encoder_state_dict(17, dim=D, hidden=256, wstd=0.05)))
+    Gn.load_state_dict(synth.to_torch(synth.generator_state_dict(18, dim=D, hidden=384, wstd=0.05)))
+    eps = torch.from_numpy(synth.hg_normal((5, D), 19)).to(d)
+    gf = torch.from_numpy(g1["vae_feats"]).to(d)
+    mean, lv, z, bias = vae.VAE(E, Gn)(gf, eps)
+    check(mean, g1["vae_mean"], what="mean"); check(lv, g1["vae_log_var"], what="log_var")
+    check(z, g1["vae_z"], what="z"); check(bias, g1["vae_bias"], what="bias")
+    m2, lv2 = E(gf)
+    check(m2, g1["vae_mean"]); check(lv2, g1["vae_log_var"])
+    check(Gn(torch.from_numpy(g1["vae_z"]).to(d)), g1["vae_bias"], what="Generator alone")
+    # prompt assembly (exact data movement + one fp32 add) and TextEncoder on embedded prompts
+    cls_tok = torch.from_numpy(g1["vae_cls_tokens"]).to(d)
+    emb = tinyA.token_embedding(cls_tok)
+    ref_emb = synth.to_torch(synth.clip_state_dict(synth.TINY, 10))["token_embedding.weight"][cls_tok.cpu()]
+    assert torch.equal(emb.cpu(), ref_emb), "token embedding gather must be exact"
+    import hoigen_amd._lib as L
+    from hoigen_amd.vae import _util_ctx, _stream_ptr
+    ctx_v = torch.from_numpy(synth.hg_normal((3, D), 21, 0.02)).to(d)
+    target = torch.from_numpy(g1["vae_target"]).to(d).int()
+    gb = torch.from_numpy(g1["vae_bias"]).to(d)
+    prompts = torch.empty(5, 16, D, device=d)
+    pre, suf = emb[:, :1].contiguous(), emb[:, 4:].contiguous()
+    h = _util_ctx.get(d)
+    rc = L.lib().hg_assemble_prompts(h, pre.data_ptr(), suf.data_ptr(), ctx_v.data_ptr(), gb.data_ptr(), target.data_ptr(),
+                                     5, 4, 16, 3, D, prompts.data_ptr(), _stream_ptr(d))
+    assert rc == 0
+    assert np.array_equal(prompts.cpu().numpy(), g1["vae_prompts"]), "prompt assembly must be bit-exact"
+    te = vae.TextEncoder(tinyA)
+    tf = te(prompts, cls_tok[target.long()])
+    check(tf, g1["vae_text_features"], what="TextEncoder(prompts)")
+    loss = vae.vae_loss(vae.l2_normalize(torch.from_numpy(g1["vae_text_features"]).to(d)), gf,
+                        torch.from_numpy(g1["vae_mean"]).to(d), torch.from_numpy(g1["vae_log_var"]).to(d))
+    assert abs(float(loss) - float(g1["vae_loss"])) <= 1e-4 * abs(float(g1["vae_loss"]))
+
+
+# ------------------------------------------------------------------------------------------------
+# ViT-B/16 (golden g2/g3/g5)
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def fullA():
+    return build_model(synth.to_torch(synth.clip_state_dict(synth.VIT_B16, 0))).to(dev())
+
+
+def test_vitb16_encode_image_vs_reference(fullA):
+    """BASELINE config 1: 4 seeded 224x224 crops vs the reference's CPU fp32 output."""
+    g = dict(np.load(f"{G}/g2_vitb16_image.npz"))
+    img = torch.from_numpy(synth.crops(4, 224, seed=1234)).to(dev())
+    out = fullA.encode_image(img)
+    assert out.shape == (4, 512) and out.dtype == torch.float16       # model.dtype on GPU (clipnet/model.py:430)
+    out32, trace = fullA.visual.forward_trace(img)
+    e = check(out32, g["encode_image"], what="encode_image ViT-B/16")
+    print(f"\nViT-B/16 encode_image rel-L2 vs reference: {e:.3e}")
+    for i in range(12):
+        check(trace[1 + i], g["cls_after_block"][i], what=f"CLS after block {i}")
+
+
+def test_vitb16_variant_c_vs_reference():
+    g = dict(np.load(f"{G}/g2_vitb16_image.npz"))
+    sd = synth.to_torch(synth.clip_state_dict(synth.VIT_B16, 0))
+    sd.update(synth.to_torch(synth.adapter_state_dict(synth.VIT_B16, 1)))
+    m = build_model(sd, use_adapter=True).to(dev())
+    img = torch.from_numpy(synth.crops(4, 224, seed=1234)).to(dev())
+    pri, mask = synth.priors(4, n=14, dim=64, n_pad=4, seed=99)
+    gl, lo = m.visual(img, (torch.from_numpy(pri).to(dev()), torch.from_numpy(mask).to(dev())))
+    assert gl.shape == (4, 512) and lo.shape == (4, 512, 14, 14) and gl.dtype == torch.float32
+    check(gl, g["c_prior_global"], what="C global")
+    check(lo.permute(0, 2, 3, 1), np.transpose(g["c_prior_local"], (0, 2, 3, 1)), what="C local [B,512,14,14]")
+    gl, lo = m.visual(img[:2], None)
+    check(gl, g["c_noprior_global"], what="C global no prior")
+    check(lo.permute(0, 2, 3, 1), np.transpose(g["c_noprior_local"], (0, 2, 3, 1)), what="C local no prior")
+
+
+def test_vitb16_encode_text_600_prompts_vs_reference(fullA, g0):
+    """BASELINE config 3: the 600 HICO prompts (+81 object, +117 verb prompts)."""
+    g3 = dict(np.load(f"{G}/g3_vitb16_text.npz"))
+    for name in ("hoi600", "obj81", "verb117"):
+        ids = clip.tokenize(g0[name]["text"])
+        assert torch.equal(ids, ids_from_g0(g0, name))
+        for trunc in (True, False):
+            fullA.truncate_text = trunc
+            e = check(fullA.encode_text(ids.to(dev())).float(), g3[name], what=f"encode_text {name} trunc={trunc}")
+        print(f"\nencode_text {name} rel-L2 vs reference: {e:.3e}")
+    fullA.truncate_text = True
+
+
+def test_vitb16_prompt_learner_text_encoder_vs_reference(fullA, g0):
+    g5 = dict(np.load(f"{G}/g5_prompt_text.npz"))
+    d = dev()
+    m = fullA
+    pl = vae.PromptLearner_hoi(g0["_classnames"]["hoi"], m).float().to(d)
+    assert pl.n_ctx == 5 and list(pl.name_lens) == g5["name_lens"].tolist()
+    with torch.no_grad():
+        pl.ctx.copy_(torch.from_numpy(synth.hg_normal((5, 512), 40, 0.02)))
+    target = torch.from_numpy(g5["target"]).to(d)
+    assert np.array_equal(pl.tokenized_prompts[target].cpu().numpy(), g5["tokenized_target"])
+    prompts = pl(torch.from_numpy(g5["bias"]).to(d), target)
+    assert prompts.shape == (32, 77, 512)
+    assert np.allclose(prompts[0].cpu().numpy(), g5["prompts_row0"], rtol=0, atol=1e-7)
+    te = vae.TextEncoder(m)
+    check(te(prompts, pl.tokenized_prompts[target]), g5["text_features"], what="TextEncoder(PromptLearner_hoi)")
+    plo = vae.PromptLearner_o(g0["_classnames"]["obj"], m).float().to(d)
+    with torch.no_grad():
+        plo.ctx.copy_(torch.from_numpy(synth.hg_normal((4, 512), 42, 0.02)))
+    tgt_o = torch.from_numpy(g5["o_target"]).to(d)
+    check(te(plo(torch.from_numpy(g5["bias"][:16]).to(d), tgt_o), plo.tokenized_prompts[tgt_o]), g5["o_text_features"],
+          what="TextEncoder(PromptLearner_o)")
+
+
+def test_vae_g4_vs_reference():
+    g = dict(np.load(f"{G}/g4_vae.npz"))
+    d = dev()
+    E, Gn, M = vae.Encoder().to(d), vae.Generator().to(d), vae.mlp_net(512, 512, 512).to(d)
+    E.load_state_dict(synth.to_torch(synth.encoder_state_dict(2)))
+    Gn.load_state_dict(synth.to_torch(synth.generator_state_dict(3)))
+    M.load_state_dict(synth.to_torch(synth.mlp_net_state_dict(4)))
+    assert list(E.state_dict()) == ["net.0.weight", "net.0.bias", "mean.weight", "mean.bias", "log_var.weight", "log_var.bias"]
+    assert list(Gn.state_dict()) == ["net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias"]
+    x = vae.l2_normalize(torch.from_numpy(synth.hg_normal((160, 512), 30)).to(d))
+    eps = torch.from_numpy(synth.hg_normal((160, 512), 31)).to(d)
+    mean, lv, z, bias = vae.VAE(E, Gn)(x, eps)
+    check(mean, g["mean"], what="mean"); check(lv, g["log_var"], what="log_var")
+    check(z, g["z"], what="z"); check(bias, g["bias"], what="bias")
+    recon = vae.l2_normalize(torch.from_numpy(synth.hg_normal((160, 512), 32)).to(d))
+    loss = vae.vae_loss(recon, x, torch.from_numpy(g["mean"]).to(d), torch.from_numpy(g["log_var"]).to(d))
+    assert abs(float(loss) - float(g["vae_loss"])) <= 1e-4 * abs(float(g["vae_loss"]))
+    check(Gn(torch.from_numpy(synth.hg_normal((64, 512), 33)).to(d)), g["gen_from_z"], what="Generator(z)")
+    f = vae.l2_normalize(torch.from_numpy(synth.hg_normal((64, 512), 34)).to(d))
+    check(M(f), g["mlp_net"], what="mlp_net")
+
+
+# ------------------------------------------------------------------------------------------------
+# HIP path vs CPU oracle on other seeded inputs / ragged sizes
+# ------------------------------------------------------------------------------------------------
+def test_vitb16_vs_oracle_ragged_batch(fullA):
+    from oracle import clip_oracle as co
+    sd = co.reference_weight_rounding(synth.clip_state_dict(synth.VIT_B16, 0))
+    img = torch.from_numpy(synth.crops(3, 224, seed=77) * 1.7 + 0.3)
+    ref = co.encode_image(sd, img)
+    check(fullA.visual.forward_trace(img.to(dev()))[0], ref.numpy(), what="B=3 vs oracle")
+    out0 = fullA.encode_image(torch.empty(0, 3, 224, 224, device=dev()))
+    assert out0.shape == (0, 512)
+
+
+def test_vae_vs_oracle_ragged_rows():
+    from oracle import clip_oracle as co, vae_oracle as vo
+    d = dev()
+    se, sg = synth.encoder_state_dict(2), synth.generator_state_dict(3)
+    E, Gn = vae.Encoder().to(d), vae.Generator().to(d)
+    E.load_state_dict(synth.to_torch(se)); Gn.load_state_dict(synth.to_torch(sg))
+    for R in (1, 129, 1000):
+        x = co.l2_normalize(torch.from_numpy(synth.hg_normal((R, 512), 50 + R)))
+        eps = torch.from_numpy(synth.hg_normal((R, 512), 60 + R))
+        ref = vo.vae_forward(co.as_tensors(se), co.as_tensors(sg), x, eps)
+        got = vae.VAE(E, Gn)(x.to(d), eps.to(d))
+        for a, b, n in zip(got, ref, ("mean", "log_var", "z", "bias")):
+            check(a, b.numpy(), what=f"{n} R={R}")
+
+
+# ------------------------------------------------------------------------------------------------
+# full-size properties (BASELINE config 2: batch 256)
+# ------------------------------------------------------------------------------------------------
+def test_batch256_invariance_and_determinism(fullA):
+    d = dev()
+    g = dict(np.load(f"{G}/g2_vitb16_image.npz"))
+    torch.manual_seed(0)
+    big = torch.randn(256, 3, 224, 224, device=d)
+    golden4 = torch.from_numpy(synth.crops(4, 224, seed=1234)).to(d)
+    big[100:104] = golden4                      # rows with a known reference answer inside the big batch
+    out = fullA.visual.forward_trace(big)[0]
+    assert torch.isfinite(out).all()
+    check(out[100:104], g["encode_image"], what="golden crops inside a 256 batch")
+    again = fullA.visual.forward_trace(big)[0]
+    assert torch.equal(out, again), "same input, same launch sequence -> bit-identical output"
+    sub = fullA.visual.forward_trace(big[96:160])[0]
+    assert torch.equal(sub, out[96:160]), "rows are independent: a crop's embedding does not depend on its batch"
+    # chunking (B > 256 is processed in chunks of 256) keeps rows identical
+    out300 = fullA.visual.forward_trace(torch.cat([big, big[:44]]))[0]
+    assert torch.equal(out300[:256], out) and torch.equal(out300[256:], out[:44])
+
+
+def test_text_truncation_is_exact_selection(fullA, g0):
+    ids = ids_from_g0(g0, "coop_hoi600", 64).to(dev())
+    fullA.truncate_text = True
+    a = fullA.encode_text(ids).float()
+    fullA.truncate_text = False
+    b = fullA.encode_text(ids).float()
+    fullA.truncate_text = True
+    whole, worst = rel_l2(a, b.cpu().numpy())
+    assert worst <= 2e-4, "running the causal tower on max(EOT)+1 positions must not change the EOT outputs"
