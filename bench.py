@@ -36,11 +36,23 @@ BATCH = 256
 GEMM_CLASS_FC = 1                  # EPI_BIAS_QGELU_F16: the c_fc GEMM (M=B*197, N=3072, K=768)
 
 
+def host_cores() -> int:
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(budget_s: float = 20.0):
     from hoigen_amd import synth
     from oracle import clip_oracle as co
 
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(host_cores(), int(os.environ.get("HG_CPU_THREADS", "64"))))
     sd = co.reference_weight_rounding(synth.clip_state_dict(synth.VIT_B16, 0))
     with torch.no_grad():
         x = torch.from_numpy(synth.crops(8, 224, seed=1234))

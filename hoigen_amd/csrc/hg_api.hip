@@ -683,6 +683,7 @@ static int encode_image_impl(hg_ctx* c, const float* x_nchw, const float* priors
     if (!c) return HG_ERR_INVALID;
     Vit& v = c->vit;
     if (!v.loaded) return fail(c, HG_ERR_NOT_LOADED, "hg_load_vit has not been called");
+    if (B == 0) return HG_OK;
     if (B < 0 || !x_nchw || !out) return fail(c, HG_ERR_INVALID, "bad arguments to encode_image");
     if (variant_c && !out_local) return fail(c, HG_ERR_INVALID, "out_local == NULL");
     if (priors && (N <= 0 || !mask)) return fail(c, HG_ERR_INVALID, "priors given but N <= 0 or mask == NULL");
@@ -769,6 +770,7 @@ int hg_encode_text_ids(hg_ctx* c, const int32_t* ids, int T, int L, float* out, 
     if (!c) return HG_ERR_INVALID;
     Text& t = c->text;
     if (!t.loaded) return fail(c, HG_ERR_NOT_LOADED, "hg_load_text has not been called");
+    if (T == 0) return HG_OK;
     if (T < 0 || !ids || !out || L < 1 || L > t.ctx) return fail(c, HG_ERR_INVALID, "bad arguments to encode_text_ids");
     hipStream_t s = (hipStream_t)stream;
     HG_HIP(hipSetDevice(c->device));
@@ -794,6 +796,7 @@ int hg_encode_text_embeds(hg_ctx* c, const float* prompts, const int32_t* eot_id
     if (!c) return HG_ERR_INVALID;
     Text& t = c->text;
     if (!t.loaded) return fail(c, HG_ERR_NOT_LOADED, "hg_load_text has not been called");
+    if (R == 0) return HG_OK;
     if (R < 0 || !prompts || !eot_idx || !out || L < 1 || L > t.ctx)
         return fail(c, HG_ERR_INVALID, "bad arguments to encode_text_embeds");
     hipStream_t s = (hipStream_t)stream;
@@ -838,6 +841,7 @@ int hg_vae_forward(hg_ctx* c, int slot, const float* x, const float* eps, int R,
     if (!c || slot < 0 || slot >= HG_MAX_SLOTS) return HG_ERR_INVALID;
     Vae& v = c->vae[slot];
     if (!v.enc || (bias && !v.gen)) return fail(c, HG_ERR_NOT_LOADED, "hg_load_vae(slot %d) incomplete", slot);
+    if (R == 0) return HG_OK;
     if (R < 0 || !x || !eps) return fail(c, HG_ERR_INVALID, "bad arguments to vae_forward");
     hipStream_t s = (hipStream_t)stream;
     HG_HIP(hipSetDevice(c->device));
@@ -877,6 +881,7 @@ int hg_generator(hg_ctx* c, int slot, const float* z, int R, float* bias, void* 
     if (!c || slot < 0 || slot >= HG_MAX_SLOTS) return HG_ERR_INVALID;
     Vae& v = c->vae[slot];
     if (!v.gen) return fail(c, HG_ERR_NOT_LOADED, "generator of slot %d not loaded", slot);
+    if (R == 0) return HG_OK;
     if (R < 0 || !z || !bias) return fail(c, HG_ERR_INVALID, "bad arguments to generator");
     hipStream_t s = (hipStream_t)stream;
     HG_HIP(hipSetDevice(c->device));
@@ -898,6 +903,7 @@ int hg_mlp_net(hg_ctx* c, int slot, const float* x, int R, float* out, void* str
     if (!c || slot < 0 || slot >= HG_MAX_SLOTS) return HG_ERR_INVALID;
     Mlp& m = c->mlp[slot];
     if (!m.loaded) return fail(c, HG_ERR_NOT_LOADED, "mlp_net slot %d not loaded", slot);
+    if (R == 0) return HG_OK;
     if (R < 0 || !x || !out) return fail(c, HG_ERR_INVALID, "bad arguments to mlp_net");
     hipStream_t s = (hipStream_t)stream;
     HG_HIP(hipSetDevice(c->device));
