@@ -5,12 +5,14 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wall -Wno-unused-function -ffp-contract=fast"
 OBJS=""
-for f in hg_gemm hg_attn hg_elem hg_adapter hg_api; do
+for f in hg_gemm hg_gemm_ring hg_attn hg_elem hg_adapter hg_api; do
   if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ hg_kernels.h -nt $f.o ] || [ hg_common.h -nt $f.o ] || [ ../../include/hoigen_amd.h -nt $f.o ]; then
-    $HIPCC $FLAGS -c $f.hip -o $f.o &
+    rm -f $f.o
+    ( $HIPCC $FLAGS -c $f.hip -o $f.o || rm -f $f.o ) &
   fi
   OBJS="$OBJS $f.o"
 done
 wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC $OBJS -o libhoigen_amd.so
+for o in $OBJS; do [ -f $o ] || { echo "compile failed: $o"; exit 1; }; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -Wl,--no-undefined $OBJS -o libhoigen_amd.so
 echo "built $(pwd)/libhoigen_amd.so"

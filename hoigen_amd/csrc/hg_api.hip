@@ -407,7 +407,7 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
 }
 
 int ensure_tower_ws(hg_ctx* c, int M, int D) {
-    const size_t Mp = rup(M, 128);
+    const size_t Mp = rup(M, 256);
     int rc = 0;
     rc |= ensure(c, c->x, Mp * D * 4);
     rc |= ensure(c, c->h, Mp * D * 2);
@@ -421,7 +421,7 @@ int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const Ada
     const int M = n_seq * L;
     float* x = (float*)c->x.p;
     half_t* h = (half_t*)c->h.p;
-    const size_t Mp = rup(M, 128);
+    const size_t Mp = rup(M, 256);
     int rc = ensure(c, c->ad32, Mp * 128 * 4);
     if (!rc) rc = ensure(c, c->ad16, Mp * 64 * 2);
     const int Nmem = ac.priors ? ac.N : L;
@@ -481,6 +481,32 @@ void hg_destroy(hg_ctx* c) {
 }
 
 const char* hg_last_error(hg_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+// Test hook: out[M,N] (fp32) (+)= epilogue(A[M,K] x W[N,K]^T) with the operands rounded to fp16 on the device.
+// kernel: 0 = dispatcher's choice, 1 = simple 128x128 kernel, 2 = persistent ring kernel.
+int hg_test_gemm(hg_ctx* c, const float* a, const float* w, const float* bias, float* out, int M, int N, int K,
+                 int epi, int kernel, void* stream) {
+    if (!c || !a || !w || !out || M <= 0) return HG_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    HG_HIP(hipSetDevice(c->device));
+    int rc = ensure(c, c->h, rup(M, 256) * K * 2);
+    if (!rc) rc = ensure(c, c->att, (size_t)N * K * 2);
+    const bool f16out = (epi == EPI_BIAS_F16 || epi == EPI_BIAS_QGELU_F16 || epi == EPI_BIAS_RELU_F16);
+    if (!rc && f16out) rc = ensure(c, c->qkv, rup(M, 256) * N * 2);
+    if (rc) return rc;
+    HG_HIP(launch_f32_to_f16(a, (half_t*)c->h.p, (size_t)M * K, s));
+    HG_HIP(launch_f32_to_f16(w, (half_t*)c->att.p, (size_t)N * K, s));
+    GemmArgs g{};
+    g.A = (half_t*)c->h.p; g.lda = K; g.W = (half_t*)c->att.p; g.bias = bias; g.M = M; g.N = N; g.K = K;
+    g.out = f16out ? c->qkv.p : (void*)out; g.ldc = N;
+    hipError_t e;
+    if (kernel == 1) e = launch_gemm_simple(epi, g, s);
+    else if (kernel == 2) e = gemm_ring_ok(g) ? launch_gemm_ring(epi, g, s) : hipErrorInvalidValue;
+    else e = launch_gemm(epi, g, s);
+    if (e != hipSuccess) return fail(c, HG_ERR_HIP, "test gemm launch failed: %s", hipGetErrorString(e));
+    if (f16out) HG_HIP(launch_f16_to_f32((const half_t*)c->qkv.p, out, (size_t)M * N, s));
+    return HG_OK;
+}
 
 int hg_profile_begin(hg_ctx* c, int gemm_class, int max_launches) {
     if (!c || max_launches < 0) return HG_ERR_INVALID;
@@ -694,9 +720,9 @@ static int encode_image_impl(hg_ctx* c, const float* x_nchw, const float* priors
         const int Bc = (B - b0 < c->max_chunk_img) ? B - b0 : c->max_chunk_img;
         const int M = Bc * L;
         int rc = ensure_tower_ws(c, M, D);
-        if (!rc) rc = ensure(c, c->head16, rup(variant_c ? M : Bc, 128) * D * 2);
+        if (!rc) rc = ensure(c, c->head16, rup(variant_c ? M : Bc, 256) * D * 2);
         if (!rc && variant_c) rc = ensure(c, c->tok32, (size_t)M * E * 4);
-        if (!rc) rc = ensure(c, c->fc, rup((size_t)Bc * G, 128) * (v.Kp > 4 * D ? v.Kp : 4 * D) * 2);
+        if (!rc) rc = ensure(c, c->fc, rup((size_t)Bc * G, 256) * (v.Kp > 4 * D ? v.Kp : 4 * D) * 2);
         if (rc) return rc;
         float* x = (float*)c->x.p;
         half_t* patches = (half_t*)c->fc.p;
@@ -778,7 +804,7 @@ int hg_encode_text_ids(hg_ctx* c, const int32_t* ids, int T, int L, float* out, 
     for (int t0 = 0; t0 < T; t0 += c->max_chunk_txt) {
         const int Tc = (T - t0 < c->max_chunk_txt) ? T - t0 : c->max_chunk_txt;
         int rc = ensure_tower_ws(c, Tc * Leff, t.D);
-        if (!rc) rc = ensure(c, c->head16, rup(Tc, 128) * t.D * 2);
+        if (!rc) rc = ensure(c, c->head16, rup(Tc, 256) * t.D * 2);
         if (!rc) rc = ensure(c, c->i32, (size_t)(Tc + 4) * 4);
         if (rc) return rc;
         int32_t* eot = (int32_t*)c->i32.p;
@@ -805,7 +831,7 @@ int hg_encode_text_embeds(hg_ctx* c, const float* prompts, const int32_t* eot_id
     for (int r0 = 0; r0 < R; r0 += c->max_chunk_txt) {
         const int Rc = (R - r0 < c->max_chunk_txt) ? R - r0 : c->max_chunk_txt;
         int rc = ensure_tower_ws(c, Rc * Leff, t.D);
-        if (!rc) rc = ensure(c, c->head16, rup(Rc, 128) * t.D * 2);
+        if (!rc) rc = ensure(c, c->head16, rup(Rc, 256) * t.D * 2);
         if (rc) return rc;
         HG_HIP(launch_add_pos(prompts + (size_t)r0 * L * t.D, L, t.pos, (float*)c->x.p, Rc, Leff, t.D, s));
         rc = text_tail(c, Rc, Leff, eot_idx + r0, out + (size_t)r0 * t.E, s);
@@ -848,7 +874,7 @@ int hg_vae_forward(hg_ctx* c, int slot, const float* x, const float* eps, int R,
     const int dim = v.dim;
     for (int r0 = 0; r0 < R; r0 += c->max_chunk_rows) {
         const int Rc = (R - r0 < c->max_chunk_rows) ? R - r0 : c->max_chunk_rows;
-        const size_t Rp = rup(Rc, 128);
+        const size_t Rp = rup(Rc, 256);
         int rc = ensure(c, c->h, Rp * dim * 2);
         if (!rc) rc = ensure(c, c->att, Rp * dim * 2);
         if (!rc) rc = ensure(c, c->qkv, Rp * v.eh * 2);
@@ -887,7 +913,7 @@ int hg_generator(hg_ctx* c, int slot, const float* z, int R, float* bias, void* 
     HG_HIP(hipSetDevice(c->device));
     for (int r0 = 0; r0 < R; r0 += c->max_chunk_rows) {
         const int Rc = (R - r0 < c->max_chunk_rows) ? R - r0 : c->max_chunk_rows;
-        const size_t Rp = rup(Rc, 128);
+        const size_t Rp = rup(Rc, 256);
         int rc = ensure(c, c->att, Rp * v.dim * 2);
         if (!rc) rc = ensure(c, c->fc, Rp * v.gh * 2);
         if (rc) return rc;
@@ -909,7 +935,7 @@ int hg_mlp_net(hg_ctx* c, int slot, const float* x, int R, float* out, void* str
     HG_HIP(hipSetDevice(c->device));
     for (int r0 = 0; r0 < R; r0 += c->max_chunk_rows) {
         const int Rc = (R - r0 < c->max_chunk_rows) ? R - r0 : c->max_chunk_rows;
-        const size_t Rp = rup(Rc, 128);
+        const size_t Rp = rup(Rc, 256);
         int rc = ensure(c, c->h, Rp * m.in * 2);
         if (!rc) rc = ensure(c, c->att, Rp * m.hid * 2);
         if (!rc) rc = ensure(c, c->qkv, Rp * m.hid * 2);

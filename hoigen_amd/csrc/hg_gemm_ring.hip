@@ -1,0 +1,369 @@
+// Persistent fp16 MFMA GEMM with an LDS ring of half-tiles (gfx950), the workhorse for the large
+// transformer GEMMs (M = B*197 = 50 432 rows at batch 256).
+//
+//   D[m][n] = sum_k A[m][k] * W[n][k]      A: activations [M,K] fp16, W: nn.Linear weight [N,K] fp16
+//
+// Geometry: tile (64*MF) x 256 x 64 with MF = 4 (256x256) or MF = 2 (128x256); 512 threads = 8 waves as
+// 2(M) x 4(N); a wave owns (32*MF... rows from each A half) x (32 columns from each W half), i.e. four
+// quadrants acc[ha][hb] of (16*MF) x 32 -> 32*MF accumulator VGPRs.  One workgroup per CU, persistent:
+// it walks its list of output tiles and treats all their K-tiles as ONE stream, so the operand
+// prefetch of the next output tile is already in flight while the current tile's epilogue runs.
+//
+// LDS ring: 2 K-tiles x {A0, A1, W0, W1} half-tile slots (A half = 32*MF rows, W half = 128 rows, 128 B
+// per row, XOR-swizzled via the DMA source address).  A slot is refilled (buffer_load ... lds, 16 B
+// per lane, no VGPR round trip) as soon as its fragments are in registers:
+//
+//   phase  reads (ds_read_b128)   MFMA quadrant     refill issued          wait before the barrier
+//   P1(t)  A0(t) W0(t)            (0,0)             A1(t+1)                vmcnt(3GA+2GB)  -> W1(t) landed
+//   P2(t)  W1(t)                  (0,1)             A0(t+2)                vmcnt(3GA+2GB)  -> A1(t) landed
+//   P3(t)  A1(t)                  (1,1)             W0(t+2)                -
+//   P4(t)  -                      (1,0)             W1(t+2)                vmcnt(2GA+3GB)  -> A0,W0(t+1)
+//
+// (GA/GB = DMA instructions per wave per A/W half-tile.)  Up to five half-tiles (80 KiB at MF = 4) are
+// in flight across the barriers; vmcnt is never drained in the loop.  Epilogue stores count in vmcnt
+// too, so the first waits after an epilogue allow for the E stores issued in between.
+//
+// The MFMA is issued with W rows as the A operand and activation rows as the B operand, so a lane
+// holds 4 consecutive output columns of one row: 8-byte (fp16) / 16-byte (fp32) epilogue accesses.
+#include <type_traits>
+
+#include "hg_kernels.h"
+
+namespace hg {
+
+__device__ __forceinline__ float quick_gelu_r(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v)); }
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_ring(const GemmArgs& p, int m, int n, f32x4 v) {
+    if (m >= p.M) return;
+    if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_BIAS_RELU_F16) {
+        if constexpr (EPI == EPI_BIAS_QGELU_F16) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = quick_gelu_r(v[r]);
+        }
+        if constexpr (EPI == EPI_BIAS_RELU_F16) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+        }
+        half4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = (half_t)v[r];
+        *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(p.out) + (size_t)m * p.ldc + n) = h;
+    } else if constexpr (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_RELU_F32) {
+        if constexpr (EPI == EPI_BIAS_RELU_F32) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+        }
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v;
+    } else if constexpr (EPI == EPI_PATCH_F32) {
+        const int b = m / p.G, t = m - b * p.G;
+        const f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (size_t)(1 + t) * p.N + n);
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + ((size_t)b * p.L + 1 + t) * p.ldc + n) = v + pe;
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void barrier_raw() { asm volatile("s_barrier" ::: "memory"); }
+
+template <int MF, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int tiles_n, const int n_tiles,
+                                                    const unsigned a_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins (buffer resources, LDS DMA): host sees just the stub
+    constexpr int BM = 64 * MF, BK = 64;
+    constexpr int AH = MF * 4096, BH = 16384;          // bytes per A / W half-tile slot
+    constexpr int STAGE = 2 * AH + 2 * BH;
+    constexpr int GA = MF / 2, GB = 2;
+    constexpr int N1 = 2 * GA + 3 * GB, N2 = 3 * GA + 2 * GB;
+    constexpr int E = 8 * MF;                          // epilogue store instructions per wave
+    constexpr bool RESID = (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_SCALE_RESID_F32);
+    // RESID at MF = 2: the residual rows are fetched one K-tile before the epilogue (64 spare VGPRs)
+    constexpr bool XPRE = RESID && MF == 2;
+    constexpr int R = XPRE ? E : 0;                    // x prefetch loads per wave
+    constexpr int BIAS_OFF = 2 * STAGE;                // bias[N] staged in LDS behind the ring
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nk = p.K / BK;
+
+    // ---- this workgroup's tile list: round r -> tile id (XCD-contiguous chunks of 32 tiles)
+    const int G = gridDim.x, bid = blockIdx.x;
+    const int slot = ((G & 7) == 0) ? (bid & 7) * (G >> 3) + (bid >> 3) : bid;
+    const int my_tiles = (n_tiles - slot + G - 1) / G;        // tiles slot, slot+G, ...
+    if (my_tiles <= 0) return;
+    const int S = my_tiles * nk;                               // K-tiles in this workgroup's stream
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (unsigned)((size_t)p.N * p.K * 2), 0x00020000);
+
+    // ---- DMA source offsets (bytes, per lane; identical for every tile and K-step)
+    int voffA[2][GA], voffW[2][GB];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < GA; ++i) {
+            const int row = (wave * GA + i) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            voffA[h][i] = (h * (BM / 2) + row) * p.lda * 2 + c * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < GB; ++i) {
+            const int row = (wave * GB + i) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            voffW[h][i] = (h * 128 + row) * p.K * 2 + c * 16;
+        }
+    }
+    // ---- load-stream state (wave-uniform): position ld_g, its tile origin and K offset
+    int ld_g = -1, ld_kt = nk - 1, ld_r = -1, ld_sA = 0, ld_sW = 0, ld_buf = 0;
+    auto ld_advance = [&]() {
+        ++ld_g;
+        if (++ld_kt == nk) {
+            ld_kt = 0;
+            ++ld_r;
+            const int id = slot + ld_r * G;
+            const int tm = id / tiles_n, tn = id - tm * tiles_n;
+            ld_sA = tm * BM * p.lda * 2;
+            ld_sW = tn * 256 * p.K * 2;
+        }
+        ld_buf = (ld_g & 1) * STAGE;
+    };
+    auto issue_A = [&](int h) {
+#pragma unroll
+        for (int i = 0; i < GA; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (HG_LDS void*)(smem + ld_buf + h * AH + (wave * GA + i) * 1024),
+                                                     16, voffA[h][i], ld_sA + ld_kt * (BK * 2), 0, 0);
+    };
+    auto issue_W = [&](int h) {
+#pragma unroll
+        for (int i = 0; i < GB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsW, (HG_LDS void*)(smem + ld_buf + 2 * AH + h * BH + (wave * GB + i) * 1024), 16, voffW[h][i],
+                ld_sW + ld_kt * (BK * 2), 0, 0);
+    };
+
+    // ---- fragment read offsets
+    const int sw = (lane >> 1) & 7;
+    int coff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) coff[ks] = ((ks * 4 + (lane >> 4)) ^ sw) << 4;
+    const int a_row = (wm * MF * 16 + (lane & 15)) * 128;
+    const int w_row = 2 * AH + (wn * 32 + (lane & 15)) * 128;
+
+    half8 xa[MF][2], wb[2][2][2];
+    auto read_A = [&](int h, int buf) {
+#pragma unroll
+        for (int f = 0; f < MF; ++f)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                xa[f][ks] = *reinterpret_cast<const half8*>(smem + buf + h * AH + a_row + f * 2048 + coff[ks]);
+    };
+    auto read_W = [&](int h, int buf) {
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                wb[h][g2][ks] = *reinterpret_cast<const half8*>(smem + buf + h * BH + w_row + g2 * 2048 + coff[ks]);
+    };
+
+    f32x4 acc[2][2][MF][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int f = 0; f < MF; ++f)
+#pragma unroll
+                    for (int g2 = 0; g2 < 2; ++g2) acc[a][b][f][g2] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto mma = [&](auto HA, auto HB) {
+        constexpr int ha = decltype(HA)::value, hb = decltype(HB)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int f = 0; f < MF; ++f)
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2)
+                    acc[ha][hb][f][g2] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[hb][g2][ks], xa[f][ks], acc[ha][hb][f][g2], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    // ---- bias -> LDS once per workgroup (epilogue reads must not touch vmcnt: a register-returning
+    // global load would wait for every older DMA of the ring)
+    {
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = tid; i < p.N / 4; i += 512)
+            *reinterpret_cast<f32x4*>(smem + BIAS_OFF + i * 16) = p.bias ? reinterpret_cast<const f32x4*>(p.bias)[i] : z;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    // ---- prologue: stream positions 0 and 1 (A1 of position 1 is issued in the first P1)
+    ld_advance();
+    issue_A(0); issue_W(0); issue_W(1); issue_A(1);
+    if (S > 1) {
+        ld_advance();
+        issue_A(0); issue_W(0); issue_W(1);
+        wait_vm<N1>();
+    } else {
+        wait_vm<GA + GB>();
+    }
+    barrier_raw();
+
+    int g = 0;
+    for (int r = 0; r < my_tiles; ++r) {
+        const int id = slot + r * G;
+        const int tm = id / tiles_n, tn = id - tm * tiles_n;
+        const int m0 = tm * BM, n0 = tn * 256;
+        zero_acc();
+        f32x4 xres[XPRE ? 2 : 1][XPRE ? 2 : 1][XPRE ? MF : 1][XPRE ? 2 : 1];
+        for (int kt = 0; kt < nk; ++kt, ++g) {
+            const int buf = (g & 1) * STAGE;
+            const bool more = g + 2 < S;          // a K-tile two positions ahead exists
+            const bool post = r > 0;               // epilogue stores of the previous tile may still be pending
+            const bool xl = XPRE && kt == nk - 1;  // residual rows are fetched during the last K-tile
+            // ---------------- P1
+            read_A(0, buf);
+            read_W(0, buf);
+            if (g + 1 < S) issue_A(1);            // A1 of position g+1 (ld state already at g+1)
+            if constexpr (XPRE) {
+                if (xl) {
+#pragma unroll
+                    for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+                        for (int f = 0; f < MF; ++f) {
+                            int m = m0 + ha * (BM / 2) + wm * MF * 16 + f * 16 + (lane & 15);
+                            m = m < p.M ? m : p.M - 1;
+#pragma unroll
+                            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                                for (int g2 = 0; g2 < 2; ++g2) {
+                                    const int n = n0 + hb * 128 + wn * 32 + g2 * 16 + 4 * (lane >> 4);
+                                    xres[ha][hb][f][g2] = *reinterpret_cast<const f32x4*>(
+                                        reinterpret_cast<const float*>(p.out) + (size_t)m * p.ldc + n);
+                                }
+                        }
+                }
+            }
+            mma(I0{}, I0{});
+            if (!more) wait_vm<0>();
+            else if (xl) wait_vm<N2 + R>();
+            else if (post && kt <= 1) wait_vm<N2 + E>();
+            else wait_vm<N2>();
+            barrier_raw();
+            // ---------------- P2
+            read_W(1, buf);
+            if (more) { ld_advance(); issue_A(0); }
+            mma(I0{}, I1{});
+            if (!more) wait_vm<0>();
+            else if (xl) wait_vm<N2 + R>();
+            else if (post && kt == 0) wait_vm<N2 + E>();
+            else wait_vm<N2>();
+            barrier_raw();
+            // ---------------- P3
+            read_A(1, buf);
+            if (more) issue_W(0);
+            mma(I1{}, I1{});
+            barrier_raw();
+            // ---------------- P4
+            if (more) issue_W(1);
+            mma(I1{}, I0{});
+            if (!more) wait_vm<0>();
+            else if (xl) wait_vm<N1 + R>();
+            else if (post && kt == 0) wait_vm<N1 + E>();
+            else wait_vm<N1>();
+            barrier_raw();
+        }
+        // ---------------- epilogue of tile r (the ring keeps prefetching the next tile meanwhile)
+#pragma unroll
+        for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+            for (int f = 0; f < MF; ++f) {
+                const int m = m0 + ha * (BM / 2) + wm * MF * 16 + f * 16 + (lane & 15);
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                    for (int g2 = 0; g2 < 2; ++g2) {
+                        const int n = n0 + hb * 128 + wn * 32 + g2 * 16 + 4 * (lane >> 4);
+                        f32x4 v = acc[ha][hb][f][g2] + *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + n * 4);
+                        if constexpr (RESID) {
+                            if (m < p.M) {
+                                if constexpr (EPI == EPI_SCALE_RESID_F32) v *= *reinterpret_cast<const f32x4*>(p.pos + n);
+                                f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n);
+                                if constexpr (XPRE) *dst = xres[ha][hb][f][g2] + v;
+                                else *dst = *dst + v;
+                            }
+                        } else {
+                            epilogue_ring<EPI>(p, m, n, v);
+                        }
+                    }
+            }
+    }
+#endif
+}
+
+template <int MF, int EPI>
+static hipError_t launch_ring_t(const GemmArgs& a, hipStream_t s) {
+    constexpr int BM = 64 * MF;
+    constexpr int RING = 2 * (2 * MF * 4096 + 2 * 16384);
+    const int LDS = RING + a.N * 4;                               // ring + bias[N]
+    if (LDS > 160 * 1024) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    static int n_cu = 256;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring<MF, EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            n_cu = prop.multiProcessorCount;
+        attr_set = true;
+    }
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / 256;
+    const int n_tiles = tiles_m * tiles_n;
+    const int grid = n_tiles < n_cu ? n_tiles : n_cu;
+    const size_t a_bytes = (size_t)tiles_m * BM * a.lda * 2;      // A is allocated with rows padded to 256
+    hipLaunchKernelGGL((gemm_ring<MF, EPI>), dim3(grid), dim3(512), LDS, s, a, tiles_n, n_tiles, (unsigned)a_bytes);
+    return hipGetLastError();
+}
+
+// Ring kernel eligibility: N % 256 == 0, K >= 256 (>= 4 K-tiles so at most one epilogue's stores are in
+// flight inside the vmcnt window), everything addressable with 32-bit byte offsets.
+bool gemm_ring_ok(const GemmArgs& a) {
+    if (a.N % 256 || a.K % 64 || a.K < 256 || a.M < 512 || a.N > 8192) return false;
+    const size_t Mp = (size_t)((a.M + 255) / 256) * 256;
+    if (Mp * a.lda * 2 >= (1ull << 31) || (size_t)a.N * a.K * 2 >= (1ull << 31)) return false;
+    return true;
+}
+
+hipError_t launch_gemm_ring(int epi, const GemmArgs& a, hipStream_t s) {
+    // 256x256 tiles when they fill the chip evenly enough, else 128x256 (N = 768 GEMMs: 591 vs 1182 tiles)
+    const int t256 = ((a.M + 255) / 256) * (a.N / 256);
+    const int rounds = (t256 + 255) / 256;
+    const bool big = t256 >= 256 && (double)t256 / (rounds * 256.0) >= 0.9;
+#define HG_RING(E)                                                         \
+    case E:                                                                \
+        return big ? launch_ring_t<4, E>(a, s) : launch_ring_t<2, E>(a, s)
+    switch (epi) {
+        HG_RING(EPI_BIAS_F16);
+        HG_RING(EPI_BIAS_QGELU_F16);
+        HG_RING(EPI_BIAS_RELU_F16);
+        HG_RING(EPI_BIAS_RESID_F32);
+        HG_RING(EPI_BIAS_F32);
+        HG_RING(EPI_PATCH_F32);
+        HG_RING(EPI_BIAS_RELU_F32);
+        HG_RING(EPI_SCALE_RESID_F32);
+        default: return hipErrorInvalidValue;
+    }
+#undef HG_RING
+}
+
+}  // namespace hg

@@ -31,8 +31,14 @@ struct GemmArgs {
 };
 
 // Requirements: N % 128 == 0, K % 64 == 0, A readable for rows < M, 16-byte aligned rows.
+// A must be allocated with its row count padded to a multiple of 256 (the ring kernel's DMA reads whole
+// tiles; rows >= M are never stored).
 hipError_t launch_gemm(int epi, const GemmArgs& a, hipStream_t s);
 double gemm_flops(const GemmArgs& a);
+// persistent ring kernel (hg_gemm_ring.hip) and the simple 128x128 kernel (hg_gemm.hip)
+bool gemm_ring_ok(const GemmArgs& a);
+hipError_t launch_gemm_ring(int epi, const GemmArgs& a, hipStream_t s);
+hipError_t launch_gemm_simple(int epi, const GemmArgs& a, hipStream_t s);
 
 // ---- attention: softmax(Q K^T / sqrt(64) [+causal]) V, head_dim 64 --------------------------
 // qkv fp16 [n_seq*L, 3*D] rows = tokens (q|k|v column blocks, head h = 64h..64h+63);

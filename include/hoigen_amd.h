@@ -195,6 +195,11 @@ int hg_workspace_bytes(hg_ctx*, uint64_t* bytes);
  * bracketed by a hipEvent pair on its own stream.  hg_profile_end synchronises and returns the mean
  * duration, the launch count, the algorithmic FLOPs of one launch (2*M*N*K) and {M,N,K}. */
 int hg_profile_begin(hg_ctx*, int gemm_class, int max_launches);
+/* Test hook for the GEMM kernels: out[M,N] fp32 = epilogue(fp16(a[M,K]) x fp16(w[N,K])^T) (for the residual
+ * epilogue `out` is read-modify-written).  epi: 0 bias->f16, 1 bias+QuickGELU->f16, 2 bias+ReLU->f16,
+ * 3 bias+residual(f32), 4 bias->f32, 6 bias+ReLU->f32.  kernel: 0 auto, 1 simple 128x128, 2 persistent ring. */
+int hg_test_gemm(hg_ctx*, const float* a, const float* w, const float* bias, float* out, int M, int N, int K,
+                 int epi, int kernel, void* stream);
 int hg_profile_end(hg_ctx*, double* avg_ms, int32_t* launches, double* flops_per_launch, int32_t* mnk);
 
 #ifdef __cplusplus
