@@ -13,18 +13,21 @@
 // per row, XOR-swizzled via the DMA source address).  A slot is refilled (buffer_load ... lds, 16 B
 // per lane, no VGPR round trip) as soon as its fragments are in registers:
 //
-//   phase  reads (ds_read_b128)   MFMA quadrant     refill issued          wait before the barrier
-//   P1(t)  A0(t) W0(t)            (0,0)             A1(t+1)                vmcnt(3GA+2GB)  -> W1(t) landed
-//   P2(t)  W1(t)                  (0,1)             A0(t+2)                vmcnt(3GA+2GB)  -> A1(t) landed
-//   P3(t)  A1(t)                  (1,1)             W0(t+2)                -
-//   P4(t)  -                      (1,0)             W1(t+2)                vmcnt(2GA+3GB)  -> A0,W0(t+1)
+//   phase  MFMA quadrant   fragment reads (for the NEXT phases)   refill issued    wait before the barrier
+//   P1(t)  (A0,W0)         W1(t)                                  A1(t+1)          vmcnt(NW) -> A1(t) landed
+//   P2(t)  (A0,W1)         A1(t)                                  A0(t+2)          -
+//   P3(t)  (A1,W0)         -                                      W0(t+2)          vmcnt(NW) -> A0,W0(t+1) landed
+//   P4(t)  (A1,W1)         A0(t+1) W0(t+1)                        W1(t+2)          vmcnt(NW) -> W1(t+1) landed
 //
-// (GA/GB = DMA instructions per wave per A/W half-tile.)  Up to five half-tiles (80 KiB at MF = 4) are
-// in flight across the barriers; vmcnt is never drained in the loop.  Epilogue stores count in vmcnt
-// too, so the first waits after an epilogue allow for the E stores issued in between.
+// NW = 2GA+2GB (GA/GB = DMA instructions per wave per A/W half-tile): four half-tiles (64 KiB at MF = 4)
+// stay in flight across the barriers; vmcnt is never drained in the loop.  Fragment reads run one phase
+// ahead of the MFMAs that consume them, so LDS latency hides under the matrix pipe.  Epilogue stores (and
+// the residual prefetch loads) count in vmcnt too, so the waits that follow them allow for E (R) more.
 //
 // The MFMA is issued with W rows as the A operand and activation rows as the B operand, so a lane
 // holds 4 consecutive output columns of one row: 8-byte (fp16) / 16-byte (fp32) epilogue accesses.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "hg_kernels.h"
@@ -154,15 +157,19 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     const int a_row = (wm * MF * 16 + (lane & 15)) * 128;
     const int w_row = 2 * AH + (wn * 32 + (lane & 15)) * 128;
 
-    half8 xa[MF][2], wb[2][2][2];
-    auto read_A = [&](int h, int buf) {
+    // Fragments are fetched one phase ahead of their MFMAs (the MFMAs of phase p cover the LDS latency of
+    // the reads for phase p+1): two A register sets (xa[0] = half 0, xa[1] = half 1) and two W sets.
+    half8 xa[2][MF][2], wb[2][2][2];
+    auto read_A = [&](auto H, int buf) {
+        constexpr int h = decltype(H)::value;
 #pragma unroll
         for (int f = 0; f < MF; ++f)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                xa[f][ks] = *reinterpret_cast<const half8*>(smem + buf + h * AH + a_row + f * 2048 + coff[ks]);
+                xa[h][f][ks] = *reinterpret_cast<const half8*>(smem + buf + h * AH + a_row + f * 2048 + coff[ks]);
     };
-    auto read_W = [&](int h, int buf) {
+    auto read_W = [&](auto H, int buf) {
+        constexpr int h = decltype(H)::value;
 #pragma unroll
         for (int g2 = 0; g2 < 2; ++g2)
 #pragma unroll
@@ -190,12 +197,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             for (int f = 0; f < MF; ++f)
 #pragma unroll
                 for (int g2 = 0; g2 < 2; ++g2)
-                    acc[ha][hb][f][g2] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[hb][g2][ks], xa[f][ks], acc[ha][hb][f][g2], 0, 0, 0);
+                    acc[ha][hb][f][g2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[hb][g2][ks], xa[ha][f][ks],
+                                                                                 acc[ha][hb][f][g2], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
+    constexpr int NW = 2 * GA + 2 * GB;    // DMA instructions younger than the half-tile a wait retires
 
     // ---- bias -> LDS once per workgroup (epilogue reads must not touch vmcnt: a register-returning
     // global load would wait for every older DMA of the ring)
@@ -211,11 +219,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     if (S > 1) {
         ld_advance();
         issue_A(0); issue_W(0); issue_W(1);
-        wait_vm<N1>();
+        wait_vm<NW>();                     // A0, W0, W1 of position 0 landed
     } else {
-        wait_vm<GA + GB>();
+        wait_vm<GA>();
     }
     barrier_raw();
+    read_A(I0{}, 0);
+    read_W(I0{}, 0);
 
     int g = 0;
     for (int r = 0; r < my_tiles; ++r) {
@@ -225,13 +235,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
         zero_acc();
         f32x4 xres[XPRE ? 2 : 1][XPRE ? 2 : 1][XPRE ? MF : 1][XPRE ? 2 : 1];
         for (int kt = 0; kt < nk; ++kt, ++g) {
-            const int buf = (g & 1) * STAGE;
+            const int buf = (g & 1) * STAGE, nbuf = STAGE - buf;
             const bool more = g + 2 < S;          // a K-tile two positions ahead exists
-            const bool post = r > 0;               // epilogue stores of the previous tile may still be pending
+            const bool post = r > 0 && kt == 0;    // epilogue stores of the previous tile may still be pending
             const bool xl = XPRE && kt == nk - 1;  // residual rows are fetched during the last K-tile
-            // ---------------- P1
-            read_A(0, buf);
-            read_W(0, buf);
+            // ---------------- P1: quadrant (0,0); fetch W1(t)
+            read_W(I1{}, buf);
             if (g + 1 < S) issue_A(1);            // A1 of position g+1 (ld state already at g+1)
             if constexpr (XPRE) {
                 if (xl) {
@@ -253,32 +262,35 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                 }
             }
             mma(I0{}, I0{});
-            if (!more) wait_vm<0>();
-            else if (xl) wait_vm<N2 + R>();
-            else if (post && kt <= 1) wait_vm<N2 + E>();
-            else wait_vm<N2>();
+            if (!more) wait_vm<0>();              // -> A1(t) landed
+            else if (xl) wait_vm<NW + R>();
+            else if (post) wait_vm<NW + E>();
+            else wait_vm<NW>();
             barrier_raw();
-            // ---------------- P2
-            read_W(1, buf);
+            // ---------------- P2: quadrant (0,1); fetch A1(t); slot A0(t) is free -> refill with A0(t+2)
+            read_A(I1{}, buf);
             if (more) { ld_advance(); issue_A(0); }
             mma(I0{}, I1{});
-            if (!more) wait_vm<0>();
-            else if (xl) wait_vm<N2 + R>();
-            else if (post && kt == 0) wait_vm<N2 + E>();
-            else wait_vm<N2>();
             barrier_raw();
-            // ---------------- P3
-            read_A(1, buf);
+            // ---------------- P3: quadrant (1,0); slot W0(t) free -> W0(t+2)
             if (more) issue_W(0);
-            mma(I1{}, I1{});
-            barrier_raw();
-            // ---------------- P4
-            if (more) issue_W(1);
             mma(I1{}, I0{});
-            if (!more) wait_vm<0>();
-            else if (xl) wait_vm<N1 + R>();
-            else if (post && kt == 0) wait_vm<N1 + E>();
-            else wait_vm<N1>();
+            if (!more) wait_vm<0>();              // -> A0(t+1), W0(t+1) landed
+            else if (xl) wait_vm<NW + R>();
+            else if (post) wait_vm<NW + E>();
+            else wait_vm<NW>();
+            barrier_raw();
+            // ---------------- P4: quadrant (1,1); fetch A0(t+1), W0(t+1); slot W1(t) free -> W1(t+2)
+            if (g + 1 < S) {
+                read_A(I0{}, nbuf);
+                read_W(I0{}, nbuf);
+            }
+            if (more) issue_W(1);
+            mma(I1{}, I1{});
+            if (!more) wait_vm<0>();              // -> W1(t+1) landed
+            else if (xl) wait_vm<NW + R>();
+            else if (post) wait_vm<NW + E>();
+            else wait_vm<NW>();
             barrier_raw();
         }
         // ---------------- epilogue of tile r (the ring keeps prefetching the next tile meanwhile)
