@@ -73,7 +73,7 @@ __device__ __forceinline__ void barrier_raw() { asm volatile("s_barrier" ::: "me
 
 template <int MF, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int tiles_n, const int n_tiles,
-                                                    const unsigned a_bytes) {
+                                                    const unsigned a_bytes, const int mode) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins (buffer resources, LDS DMA): host sees just the stub
     constexpr int BM = 64 * MF, BK = 64;
     constexpr int AH = MF * 4096, BH = 16384;          // bytes per A / W half-tile slot
@@ -130,8 +130,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             ++ld_r;
             const int id = slot + ld_r * G;
             const int tm = id / tiles_n, tn = id - tm * tiles_n;
-            ld_sA = tm * BM * p.lda * 2;
-            ld_sW = tn * 256 * p.K * 2;
+            ld_sA = (mode & 1) ? 0 : tm * BM * p.lda * 2;     // mode 1 (timing experiment): every tile reads tile 0
+            ld_sW = (mode & 1) ? 0 : tn * 256 * p.K * 2;
         }
         ld_buf = (ld_g & 1) * STAGE;
     };
@@ -190,6 +190,16 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     };
     auto mma = [&](auto HA, auto HB) {
         constexpr int ha = decltype(HA)::value, hb = decltype(HB)::value;
+        if (mode & 2) {   // timing experiment: no MFMAs (operands kept live)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int f = 0; f < MF; ++f) asm volatile("" ::"v"(xa[ha][f][ks]));
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) asm volatile("" ::"v"(wb[hb][g2][ks]));
+            }
+            return;
+        }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -294,6 +304,60 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             barrier_raw();
         }
         // ---------------- epilogue of tile r (the ring keeps prefetching the next tile meanwhile)
+        if (mode & 4) {   // timing experiment: no epilogue
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int f = 0; f < MF; ++f)
+#pragma unroll
+                        for (int g2 = 0; g2 < 2; ++g2) asm volatile("" ::"v"(acc[a][b][f][g2]));
+            continue;
+        }
+        constexpr bool F16OUT = (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_BIAS_RELU_F16);
+        if constexpr (F16OUT) {
+            // fp16 outputs: a lane holds 4 consecutive columns (8 B) of one row.  v_permlane16_swap pairs the
+            // accumulator tiles f, f+1 (same columns, rows 16 apart) so that even 16-lane groups end up with 8
+            // consecutive columns of tile f's row and odd groups with 8 of tile f+1's row: 16-byte stores,
+            // half the store instructions (the tail is store-issue bound).
+            const int q = lane >> 4;
+            half_t* outp = reinterpret_cast<half_t*>(p.out);
+#pragma unroll
+            for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+                for (int f = 0; f < MF; f += 2) {
+                    const int mX = m0 + ha * (BM / 2) + wm * MF * 16 + f * 16 + (lane & 15);
+                    const int m = mX + ((q & 1) ? 16 : 0);
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                        for (int g2 = 0; g2 < 2; ++g2) {
+                            const int nb = n0 + hb * 128 + wn * 32 + g2 * 16;
+                            const f32x4 bv = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (nb + 4 * q) * 4);
+                            f32x4 vx = acc[ha][hb][f][g2] + bv, vy = acc[ha][hb][f + 1][g2] + bv;
+                            if constexpr (EPI == EPI_BIAS_QGELU_F16) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { vx[r] = quick_gelu_r(vx[r]); vy[r] = quick_gelu_r(vy[r]); }
+                            }
+                            if constexpr (EPI == EPI_BIAS_RELU_F16) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { vx[r] = fmaxf(vx[r], 0.f); vy[r] = fmaxf(vy[r], 0.f); }
+                            }
+                            half4 hx, hy;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { hx[r] = (half_t)vx[r]; hy[r] = (half_t)vy[r]; }
+                            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                            const u32x2 ux = __builtin_bit_cast(u32x2, hx), uy = __builtin_bit_cast(u32x2, hy);
+                            const auto s0 = __builtin_amdgcn_permlane16_swap(ux[0], uy[0], false, false);
+                            const auto s1 = __builtin_amdgcn_permlane16_swap(ux[1], uy[1], false, false);
+                            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                            const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                            if (m < p.M)
+                                *reinterpret_cast<u32x4*>(outp + (size_t)m * p.ldc + nb + 4 * (q & ~1)) = o;
+                        }
+                }
+        } else {
 #pragma unroll
         for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
@@ -317,6 +381,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                         }
                     }
             }
+        }
     }
 #endif
 }
@@ -343,7 +408,8 @@ static hipError_t launch_ring_t(const GemmArgs& a, hipStream_t s) {
     const int n_tiles = tiles_m * tiles_n;
     const int grid = n_tiles < n_cu ? n_tiles : n_cu;
     const size_t a_bytes = (size_t)tiles_m * BM * a.lda * 2;      // A is allocated with rows padded to 256
-    hipLaunchKernelGGL((gemm_ring<MF, EPI>), dim3(grid), dim3(512), LDS, s, a, tiles_n, n_tiles, (unsigned)a_bytes);
+    static const int mode = []() { const char* e = getenv("HG_RING_MODE"); return e ? atoi(e) : 0; }();
+    hipLaunchKernelGGL((gemm_ring<MF, EPI>), dim3(grid), dim3(512), LDS, s, a, tiles_n, n_tiles, (unsigned)a_bytes, mode);
     return hipGetLastError();
 }
 
