@@ -3,39 +3,45 @@
 // nn.MultiheadAttention (clipnet/model.py:171,181-183).  The [L,L] score matrix
 // never leaves registers.
 //
-// One workgroup (4 waves) per (sequence, head).  K and V rows (128 B each) are DMA'd global -> LDS
-// (global_load_lds, swizzled on the source address).  Each wave owns 32-query tiles and computes
-//   S^T = K Q^T          (v_mfma_f32_32x32x16_f16, keys on MFMA rows, queries on lanes)
-// so a lane holds one query's scores: row max / sum are register reductions plus one cross-half
-// exchange.  P^T (fp16) is then directly the B operand of
-//   O^T = V^T P^T
-// with V^T fragments fetched by the hardware transposing read ds_read_b64_tr_b16 in the k-order the
-// accumulator layout dictates.  Softmax statistics and accumulation are fp32.
+// One workgroup per (sequence, head) with ONE WAVE PER 32-QUERY TILE (7 waves for L = 197, 3 for
+// L = 77).  K and V rows (128 B each) are DMA'd global -> LDS (global_load_lds, XOR-swizzled on the
+// source address).  Each wave walks the key tiles with an online softmax:
+//   S^T = K_tile Q^T      v_mfma_f32_32x32x16_f16, keys on MFMA rows, queries on lanes -> a lane holds
+//                         one query's 16 scores of the tile: max / sum are register reductions plus
+//                         one cross-half exchange
+//   O^T += V_tile^T P^T   P^T (fp16) is directly the B operand; V^T fragments come from the hardware
+//                         transposing read ds_read_b64_tr_b16 in the k-order the accumulator layout
+//                         dictates
+// The running max only triggers a rescale of O when some query's max actually grew (wave-uniform
+// branch).  Softmax statistics and accumulation are fp32; masking (keys >= L, causal diagonal) is
+// applied only on the tiles that need it.
 #include "hg_kernels.h"
 
 namespace hg {
 
 static constexpr int HD = 64;            // head dim
 static constexpr int ROWB = HD * 2;      // bytes per K/V row in LDS
+static constexpr int TILEB = 32 * ROWB;  // bytes per 32-key tile
 
 __device__ __forceinline__ int swz_k(int row) { return (row >> 1) & 7; }          // b128 row reads
 __device__ __forceinline__ int swz_v(int row) { return ((row >> 1) & 1) << 2; }   // tr_b16 reads
 
-template <int NKT, bool CAUSAL>
-__global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
-                                                        int L, int heads) {
+template <bool CAUSAL>
+__global__ __launch_bounds__(448) void attention_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
+                                                        int L, int heads, int nkt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
-    char* Vs = smem + NKT * 32 * ROWB;
+    char* Vs = smem + nkt * TILEB;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = blockDim.x >> 6;
     const int D = heads * HD;
     const int seq = blockIdx.x / heads, head = blockIdx.x - seq * heads;
     const size_t ld = (size_t)3 * D;
     const half_t* base = qkv + (size_t)seq * L * ld + head * HD;
 
     // ---- stage K and V: piece = 8 rows x 128 B; lane -> (row = l>>3, chunk' = l&7)
-    for (int piece = wave; piece < NKT * 4; piece += 4) {
+    for (int piece = wave; piece < nkt * 4; piece += nwaves) {
         const int row = piece * 8 + (lane >> 3);
         const int src_row = row < L ? row : L - 1;
         const half_t* rp = base + (size_t)src_row * ld;
@@ -44,123 +50,134 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
         glds16(rp + 2 * D + ((cp ^ swz_v(row)) << 3), Vs + piece * 1024);
     }
 
+    // ---- this wave's query tile; Q fragments straight from global (B operand: lane = query, k = d)
+    const int qt = wave;
+    const int qcol = lane & 31, hh = lane >> 5;
+    const int q = qt * 32 + qcol;
+    const half_t* qp = base + (size_t)(q < L ? q : L - 1) * ld + hh * 8;
+    half8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const half8*>(qp + ks * 16);
+
     __syncthreads();   // K/V landed (the barrier's fence waits for the LDS-DMA: vmcnt(0))
 
-    const int qcol = lane & 31, hh = lane >> 5;
-    const float sl2 = 0.125f * 1.4426950408889634f;   // head_dim^-0.5 * log2(e)
-
-    for (int qt = wave; qt * 32 < L; qt += 4) {
-        // Q fragments straight from global: B operand, lane = query, k = d
-        const int q = qt * 32 + qcol;
-        const half_t* qp = base + (size_t)(q < L ? q : L - 1) * ld + hh * 8;
-        half8 qf[4];
+    // lane-constant LDS offsets
+    int k_off[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const half8*>(qp + ks * 16);
-
-        const int nkt = CAUSAL ? (qt + 1 < NKT ? qt + 1 : NKT) : NKT;
-        f32x16 s[NKT];
+    for (int ks = 0; ks < 4; ++ks) k_off[ks] = qcol * ROWB + (((2 * ks + hh) ^ swz_k(qcol)) << 4);
+    const int gi = lane >> 4, l16 = lane & 15;
+    const int vq = l16 >> 2, vp = l16 & 3;   // tr-read role: row vq of the 4x16 block, columns 4*vp..4*vp+3
+    int v_off[2];
+    {
+        const int key0 = 4 * (gi >> 1) + vq;   // + kt*32 + 16*sstep (+8 for the second read)
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-            if (kt < nkt) {
-                const int krow = kt * 32 + qcol;   // this lane's K row for the A fragment
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int c = (2 * ks + hh) ^ swz_k(krow);
-                    const half8 kf = *reinterpret_cast<const half8*>(Ks + krow * ROWB + (c << 4));
-                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kt], 0, 0, 0);
-                }
-            }
+        for (int dt = 0; dt < 2; ++dt) {
+            const int chunk = dt * 4 + (gi & 1) * 2 + (vp >> 1);
+            v_off[dt] = key0 * ROWB + ((chunk ^ swz_v(key0)) << 4) + (vp & 1) * 8;
         }
-        // ---- softmax over keys: lane holds keys kt*32 + (r&3) + 8*(r>>2) + 4*hh of query q
-        float mx = -INFINITY;
+    }
+
+    const float c = 0.125f * 1.4426950408889634f;   // head_dim^-0.5 * log2(e)
+    float m = -1.0e30f, lsum = 0.f;
+    f32x16 o[2];
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+
+    const int kt_end = CAUSAL ? (qt + 1 < nkt ? qt + 1 : nkt) : nkt;
+    for (int kt = 0; kt < kt_end; ++kt) {
+        // ---- S^T tile: lane holds keys kt*32 + (r&3) + 8*(r>>2) + 4*hh of query q
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        const char* kb = Ks + kt * TILEB;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const half8 kf = *reinterpret_cast<const half8*>(kb + k_off[ks]);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
+        }
+        const bool need_mask = (kt * 32 + 32 > L) || (CAUSAL && kt == qt);   // wave-uniform
+        if (need_mask) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const bool ok = (kt < nkt) && key < L && (!CAUSAL || key <= q);
-                s[kt][r] = ok ? s[kt][r] : -INFINITY;
-                mx = fmaxf(mx, s[kt][r]);
+                const bool ok = key < L && (!CAUSAL || key <= q);
+                s[r] = ok ? s[r] : -INFINITY;
             }
         }
+        float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+#pragma unroll
+        for (int r = 4; r < 16; r += 4) mx = fmaxf(mx, fmaxf(fmaxf(s[r], s[r + 1]), fmaxf(s[r + 2], s[r + 3])));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
-        half8 pf[NKT][2];
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = exp2f((s[kt][r] - mx) * sl2);
-                sum += e;
-                pf[kt][r >> 3][r & 7] = (half_t)e;
-            }
-        }
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
-
-        // ---- O^T[d][q] = sum_key V[key][d] P[q][key]
-        f32x16 o[2];
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-        const int gi = lane >> 4, l16 = lane & 15;
-        const int vq = l16 >> 2, vp = l16 & 3;   // tr-read address role: row vq, columns 4*vp..4*vp+3
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-            if (kt < nkt) {
-#pragma unroll
-                for (int sstep = 0; sstep < 2; ++sstep) {
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
-                        // element j of lane half hh must be key 16s + 8(j>>2) + 4hh + (j&3)
-                        const int key0 = kt * 32 + 16 * sstep + 4 * (gi >> 1) + vq;
-                        const int chunk = dt * 4 + (gi & 1) * 2 + (vp >> 1);
-                        const int a0 = key0 * ROWB + ((chunk ^ swz_v(key0)) << 4) + (vp & 1) * 8;
-                        const int key1 = key0 + 8;
-                        const int a1 = key1 * ROWB + ((chunk ^ swz_v(key1)) << 4) + (vp & 1) * 8;
-                        const fp16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((HG_LDS fp16x4_t*)(Vs + a0));
-                        const fp16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((HG_LDS fp16x4_t*)(Vs + a1));
-                        half8 vf;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            vf[e] = (half_t)v0[e];
-                            vf[4 + e] = (half_t)v1[e];
-                        }
-                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kt][sstep], o[dt], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        // ---- store: lane = query q, d = dt*32 + (r&3) + 8*(r>>2) + 4*hh
-        if (q < L) {
-            half_t* op = out + ((size_t)seq * L + q) * D + head * HD;
+        if (__any(mx > m)) {                 // some query's running max grew: rescale (wave-uniform branch)
+            const float mn = fmaxf(m, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
+            m = mn;
+            lsum *= alpha;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    half4 h;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) h[e] = (half_t)(o[dt][g * 4 + e] * inv);
-                    *reinterpret_cast<half4*>(op + dt * 32 + 8 * g + 4 * hh) = h;
-                }
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
         }
+        const float mc = m * c;
+        half8 pf[2];
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(s[r], c, -mc));
+            ps += e;
+            pf[r >> 3][r & 7] = (half_t)e;
+        }
+        lsum += ps;
+        // ---- O^T[d][q] += sum_key V[key][d] P[q][key]; element j of lane half hh is key 16s + 8(j>>2) + 4hh + (j&3)
+        const char* vb = Vs + kt * TILEB;
+#pragma unroll
+        for (int sstep = 0; sstep < 2; ++sstep) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const char* va = vb + sstep * (16 * ROWB) + v_off[dt];
+                const fp16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((HG_LDS fp16x4_t*)(va));
+                const fp16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((HG_LDS fp16x4_t*)(va + 8 * ROWB));
+                half8 vf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    vf[e] = (half_t)v0[e];
+                    vf[4 + e] = (half_t)v1[e];
+                }
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[sstep], o[dt], 0, 0, 0);
+            }
+        }
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    const float inv = 1.0f / lsum;
+    // ---- store: lane = query q, d = dt*32 + (r&3) + 8*(r>>2) + 4*hh
+    if (q < L) {
+        half_t* op = out + ((size_t)seq * L + q) * D + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                half4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = (half_t)(o[dt][g * 4 + e] * inv);
+                *reinterpret_cast<half4*>(op + dt * 32 + 8 * g + 4 * hh) = h;
+            }
     }
 }
 
-template <int NKT, bool CAUSAL>
+template <bool CAUSAL>
 static hipError_t launch_t(const half_t* qkv, half_t* out, int n_seq, int L, int heads, hipStream_t s) {
-    const int lds = 2 * NKT * 32 * ROWB;
+    const int nkt = (L + 31) / 32;
+    const int lds = 2 * nkt * TILEB;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<NKT, CAUSAL>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<CAUSAL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 7 * TILEB);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((attention_kernel<NKT, CAUSAL>), dim3(n_seq * heads), dim3(256), lds, s, qkv, out, L, heads);
+    hipLaunchKernelGGL((attention_kernel<CAUSAL>), dim3(n_seq * heads), dim3(64 * nkt), lds, s, qkv, out, L, heads, nkt);
     return hipGetLastError();
 }
 
@@ -168,20 +185,7 @@ hipError_t launch_attention(const half_t* qkv, half_t* out, int n_seq, int L, in
                             hipStream_t s) {
     if (n_seq <= 0) return hipSuccess;
     if (L < 1 || L > 224) return hipErrorInvalidValue;
-    const int nkt = (L + 31) / 32;
-#define HG_ATT(N)                                                                   \
-    return causal ? launch_t<N, true>(qkv, out, n_seq, L, heads, s)                  \
-                  : launch_t<N, false>(qkv, out, n_seq, L, heads, s)
-    switch (nkt) {
-        case 1: HG_ATT(1);
-        case 2: HG_ATT(2);
-        case 3: HG_ATT(3);
-        case 4: HG_ATT(4);
-        case 5: HG_ATT(5);
-        case 6: HG_ATT(6);
-        default: HG_ATT(7);
-    }
-#undef HG_ATT
+    return causal ? launch_t<true>(qkv, out, n_seq, L, heads, s) : launch_t<false>(qkv, out, n_seq, L, heads, s);
 }
 
 }  // namespace hg
