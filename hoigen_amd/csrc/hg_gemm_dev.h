@@ -1,0 +1,44 @@
+// Device helpers shared by the persistent ring GEMM kernels (hg_gemm_ring.hip, hg_gemm_ring2.hip).
+#pragma once
+#include "hg_kernels.h"
+
+namespace hg {
+
+__device__ __forceinline__ float quick_gelu_r(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v)); }
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_ring(const GemmArgs& p, int m, int n, f32x4 v) {
+    if (m >= p.M) return;
+    if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_BIAS_RELU_F16) {
+        if constexpr (EPI == EPI_BIAS_QGELU_F16) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = quick_gelu_r(v[r]);
+        }
+        if constexpr (EPI == EPI_BIAS_RELU_F16) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+        }
+        half4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = (half_t)v[r];
+        *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(p.out) + (size_t)m * p.ldc + n) = h;
+    } else if constexpr (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_RELU_F32) {
+        if constexpr (EPI == EPI_BIAS_RELU_F32) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+        }
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v;
+    } else if constexpr (EPI == EPI_PATCH_F32) {
+        const int b = m / p.G, t = m - b * p.G;
+        const f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (size_t)(1 + t) * p.N + n);
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + ((size_t)b * p.L + 1 + t) * p.ldc + n) = v + pe;
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void barrier_raw() { asm volatile("s_barrier" ::: "memory"); }
+
+}  // namespace hg

@@ -13,16 +13,18 @@
 // per row, XOR-swizzled via the DMA source address).  A slot is refilled (buffer_load ... lds, 16 B
 // per lane, no VGPR round trip) as soon as its fragments are in registers:
 //
-//   phase  MFMA quadrant   fragment reads (for the NEXT phases)   refill issued    wait before the barrier
-//   P1(t)  (A0,W0)         W1(t)                                  A1(t+1)          vmcnt(NW) -> A1(t) landed
-//   P2(t)  (A0,W1)         A1(t)                                  A0(t+2)          -
-//   P3(t)  (A1,W0)         -                                      W0(t+2)          vmcnt(NW) -> A0,W0(t+1) landed
-//   P4(t)  (A1,W1)         A0(t+1) W0(t+1)                        W1(t+2)          vmcnt(NW) -> W1(t+1) landed
+//   phase  fetch segment: LDS reads -> regs   DMA refill issued   vmcnt before its barrier      MFMA segment
+//   P1(t)  A0(t) W0(t)                         A1(t+1)             (3GA+2GB) -> W1(t) landed     quadrant (A0,W0)
+//   P2(t)  W1(t)                               A0(t+2)             (3GA+2GB) -> A1(t) landed     quadrant (A0,W1)
+//   P3(t)  A1(t)                               W0(t+2)             -                             quadrant (A1,W1)
+//   P4(t)  -                                   W1(t+2)             (2GA+3GB) -> A0,W0(t+1)       quadrant (A1,W0)
 //
-// NW = 2GA+2GB (GA/GB = DMA instructions per wave per A/W half-tile): four half-tiles (64 KiB at MF = 4)
-// stay in flight across the barriers; vmcnt is never drained in the loop.  Fragment reads run one phase
-// ahead of the MFMAs that consume them, so LDS latency hides under the matrix pipe.  Epilogue stores (and
-// the residual prefetch loads) count in vmcnt too, so the waits that follow them allow for E (R) more.
+// (GA/GB = DMA instructions per wave per A/W half-tile.)  Every phase is [fetch segment] barrier [16 MFMAs]
+// barrier, and waves 4-7 run one barrier interval behind waves 0-3: on each SIMD one wave is always in a
+// fetch segment (LDS reads, DMA issue, counted waits) while its partner feeds the matrix pipe.  Up to five
+// half-tiles (80 KiB at MF = 4) are in flight across the barriers; vmcnt is never drained in the loop.
+// Epilogue stores (and the residual prefetch loads) count in vmcnt too, so the waits that follow them allow
+// for E (R) more.
 //
 // The MFMA is issued with W rows as the A operand and activation rows as the B operand, so a lane
 // holds 4 consecutive output columns of one row: 8-byte (fp16) / 16-byte (fp32) epilogue accesses.
@@ -30,46 +32,9 @@
 
 #include <type_traits>
 
-#include "hg_kernels.h"
+#include "hg_gemm_dev.h"
 
 namespace hg {
-
-__device__ __forceinline__ float quick_gelu_r(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v)); }
-
-template <int EPI>
-__device__ __forceinline__ void epilogue_ring(const GemmArgs& p, int m, int n, f32x4 v) {
-    if (m >= p.M) return;
-    if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_BIAS_RELU_F16) {
-        if constexpr (EPI == EPI_BIAS_QGELU_F16) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = quick_gelu_r(v[r]);
-        }
-        if constexpr (EPI == EPI_BIAS_RELU_F16) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
-        }
-        half4 h;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = (half_t)v[r];
-        *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(p.out) + (size_t)m * p.ldc + n) = h;
-    } else if constexpr (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_RELU_F32) {
-        if constexpr (EPI == EPI_BIAS_RELU_F32) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
-        }
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v;
-    } else if constexpr (EPI == EPI_PATCH_F32) {
-        const int b = m / p.G, t = m - b * p.G;
-        const f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (size_t)(1 + t) * p.N + n);
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + ((size_t)b * p.L + 1 + t) * p.ldc + n) = v + pe;
-    }
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-__device__ __forceinline__ void barrier_raw() { asm volatile("s_barrier" ::: "memory"); }
 
 template <int MF, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int tiles_n, const int n_tiles,
@@ -157,16 +122,14 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     const int a_row = (wm * MF * 16 + (lane & 15)) * 128;
     const int w_row = 2 * AH + (wn * 32 + (lane & 15)) * 128;
 
-    // Fragments are fetched one phase ahead of their MFMAs (the MFMAs of phase p cover the LDS latency of
-    // the reads for phase p+1): two A register sets (xa[0] = half 0, xa[1] = half 1) and two W sets.
-    half8 xa[2][MF][2], wb[2][2][2];
-    auto read_A = [&](auto H, int buf) {
-        constexpr int h = decltype(H)::value;
+    // Fragment registers: one A set (half 0 in P1-P2, half 1 in P3-P4) and both W halves.
+    half8 xa[MF][2], wb[2][2][2];
+    auto read_A = [&](int h, int buf) {
 #pragma unroll
         for (int f = 0; f < MF; ++f)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                xa[h][f][ks] = *reinterpret_cast<const half8*>(smem + buf + h * AH + a_row + f * 2048 + coff[ks]);
+                xa[f][ks] = *reinterpret_cast<const half8*>(smem + buf + h * AH + a_row + f * 2048 + coff[ks]);
     };
     auto read_W = [&](auto H, int buf) {
         constexpr int h = decltype(H)::value;
@@ -194,7 +157,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-                for (int f = 0; f < MF; ++f) asm volatile("" ::"v"(xa[ha][f][ks]));
+                for (int f = 0; f < MF; ++f) asm volatile("" ::"v"(xa[f][ks]));
 #pragma unroll
                 for (int g2 = 0; g2 < 2; ++g2) asm volatile("" ::"v"(wb[hb][g2][ks]));
             }
@@ -207,13 +170,22 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             for (int f = 0; f < MF; ++f)
 #pragma unroll
                 for (int g2 = 0; g2 < 2; ++g2)
-                    acc[ha][hb][f][g2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[hb][g2][ks], xa[ha][f][ks],
-                                                                                 acc[ha][hb][f][g2], 0, 0, 0);
+                    acc[ha][hb][f][g2] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[hb][g2][ks], xa[f][ks], acc[ha][hb][f][g2], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    constexpr int NW = 2 * GA + 2 * GB;    // DMA instructions younger than the half-tile a wait retires
+    // end of a fetch segment: this wave's fragment reads are complete, then the workgroup barrier; the
+    // sched_barrier keeps the compiler from hoisting the (register-only) MFMAs into the fetch segment
+    auto sync_fetch = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto sync_mma = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        barrier_raw();
+    };
 
     // ---- bias -> LDS once per workgroup (epilogue reads must not touch vmcnt: a register-returning
     // global load would wait for every older DMA of the ring)
@@ -229,13 +201,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     if (S > 1) {
         ld_advance();
         issue_A(0); issue_W(0); issue_W(1);
-        wait_vm<NW>();                     // A0, W0, W1 of position 0 landed
+        wait_vm<N1>();                     // A0, W0 of position 0 landed
     } else {
-        wait_vm<GA>();
+        wait_vm<GA + GB>();
     }
     barrier_raw();
-    read_A(I0{}, 0);
-    read_W(I0{}, 0);
+    // Stagger: waves 4-7 (the second wave of every SIMD) run one barrier interval behind waves 0-3, so a
+    // SIMD always has one wave in a fetch segment (LDS reads, DMA issue, waits) and one in an MFMA segment.
+    const bool late = (wave >= 4) && !(mode & 8);
+    if (late) barrier_raw();
 
     int g = 0;
     for (int r = 0; r < my_tiles; ++r) {
@@ -245,12 +219,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
         zero_acc();
         f32x4 xres[XPRE ? 2 : 1][XPRE ? 2 : 1][XPRE ? MF : 1][XPRE ? 2 : 1];
         for (int kt = 0; kt < nk; ++kt, ++g) {
-            const int buf = (g & 1) * STAGE, nbuf = STAGE - buf;
+            const int buf = (g & 1) * STAGE;
             const bool more = g + 2 < S;          // a K-tile two positions ahead exists
-            const bool post = r > 0 && kt == 0;    // epilogue stores of the previous tile may still be pending
+            const bool post = r > 0;               // epilogue stores of the previous tile may still be pending
             const bool xl = XPRE && kt == nk - 1;  // residual rows are fetched during the last K-tile
-            // ---------------- P1: quadrant (0,0); fetch W1(t)
-            read_W(I1{}, buf);
+            // ---------------- P1: fetch A0(t), W0(t); refill A1(t+1); then quadrant (0,0)
+            read_A(0, buf);
+            read_W(I0{}, buf);
             if (g + 1 < S) issue_A(1);            // A1 of position g+1 (ld state already at g+1)
             if constexpr (XPRE) {
                 if (xl) {
@@ -271,37 +246,38 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                         }
                 }
             }
+            if (!more) wait_vm<0>();              // -> W1(t) landed (read in P2)
+            else if (xl) wait_vm<N2 + R>();
+            else if (post && kt <= 1) wait_vm<N2 + E>();
+            else wait_vm<N2>();
+            sync_fetch();
             mma(I0{}, I0{});
-            if (!more) wait_vm<0>();              // -> A1(t) landed
-            else if (xl) wait_vm<NW + R>();
-            else if (post) wait_vm<NW + E>();
-            else wait_vm<NW>();
-            barrier_raw();
-            // ---------------- P2: quadrant (0,1); fetch A1(t); slot A0(t) is free -> refill with A0(t+2)
-            read_A(I1{}, buf);
+            sync_mma();
+            // ---------------- P2: fetch W1(t); slot A0(t) is free -> A0(t+2); quadrant (0,1)
+            read_W(I1{}, buf);
             if (more) { ld_advance(); issue_A(0); }
+            if (!more) wait_vm<0>();              // -> A1(t) landed (read in P3)
+            else if (xl) wait_vm<N2 + R>();
+            else if (post && kt == 0) wait_vm<N2 + E>();
+            else wait_vm<N2>();
+            sync_fetch();
             mma(I0{}, I1{});
-            barrier_raw();
-            // ---------------- P3: quadrant (1,0); slot W0(t) free -> W0(t+2)
+            sync_mma();
+            // ---------------- P3: fetch A1(t); slot W0(t) free -> W0(t+2); quadrant (1,1)
+            read_A(1, buf);
             if (more) issue_W(0);
-            mma(I1{}, I0{});
-            if (!more) wait_vm<0>();              // -> A0(t+1), W0(t+1) landed
-            else if (xl) wait_vm<NW + R>();
-            else if (post) wait_vm<NW + E>();
-            else wait_vm<NW>();
-            barrier_raw();
-            // ---------------- P4: quadrant (1,1); fetch A0(t+1), W0(t+1); slot W1(t) free -> W1(t+2)
-            if (g + 1 < S) {
-                read_A(I0{}, nbuf);
-                read_W(I0{}, nbuf);
-            }
-            if (more) issue_W(1);
+            sync_fetch();
             mma(I1{}, I1{});
-            if (!more) wait_vm<0>();              // -> W1(t+1) landed
-            else if (xl) wait_vm<NW + R>();
-            else if (post) wait_vm<NW + E>();
-            else wait_vm<NW>();
-            barrier_raw();
+            sync_mma();
+            // ---------------- P4: slot W1(t) free -> W1(t+2); quadrant (1,0)
+            if (more) issue_W(1);
+            if (!more) wait_vm<0>();              // -> A0(t+1), W0(t+1) landed (read in the next P1)
+            else if (xl) wait_vm<N1 + R>();
+            else if (post && kt == 0) wait_vm<N1 + E>();
+            else wait_vm<N1>();
+            sync_fetch();
+            mma(I1{}, I0{});
+            sync_mma();
         }
         // ---------------- epilogue of tile r (the ring keeps prefetching the next tile meanwhile)
         if (mode & 4) {   // timing experiment: no epilogue
@@ -383,6 +359,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             }
         }
     }
+    if (!late) barrier_raw();   // balances the extra barrier of the late waves
 #endif
 }
 
@@ -426,7 +403,9 @@ hipError_t launch_gemm_ring(int epi, const GemmArgs& a, hipStream_t s) {
     // 256x256 tiles when they fill the chip evenly enough, else 128x256 (N = 768 GEMMs: 591 vs 1182 tiles)
     const int t256 = ((a.M + 255) / 256) * (a.N / 256);
     const int rounds = (t256 + 255) / 256;
-    const bool big = t256 >= 256 && (double)t256 / (rounds * 256.0) >= 0.9;
+    static const int force_big = []() { const char* e = getenv("HG_RING_BIG"); return e ? atoi(e) : 0; }();
+    const bool big = force_big == 1 ? true : (force_big == 2 || force_big == 3) ? false : (t256 >= 256 && (double)t256 / (rounds * 256.0) >= 0.9);
+    if (!big && force_big != 3 && gemm_ring2_ok(a)) return launch_gemm_ring2(epi, a, s);   // 128x256, two-phase
 #define HG_RING(E)                                                         \
     case E:                                                                \
         return big ? launch_ring_t<4, E>(a, s) : launch_ring_t<2, E>(a, s)

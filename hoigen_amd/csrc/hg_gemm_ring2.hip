@@ -1,0 +1,348 @@
+// Persistent fp16 MFMA GEMM, 128 x 256 x 64 tiles, two phases per K-tile, three-stage LDS ring (gfx950).
+//
+// Used where 256x256 tiles would quantise badly over the 256 CUs: the N = 768 GEMMs of the ViT block
+// (attention out-projection, MLP c_proj; 1182 tiles = 4.6 rounds instead of 591 = 2.3) and mid-sized
+// problems.  Same conventions as hg_gemm_ring.hip (W rows as the MFMA A operand, activations as B, so a
+// lane holds 4 consecutive output columns of one row; XOR-swizzled LDS images written by buffer_load...lds;
+// bias staged in LDS; persistent workgroups walking their tiles as one K-tile stream).
+//
+// 512 threads = 8 waves as 2(M) x 4(N); a wave owns 32 rows of each A half (64 rows) and 32 columns of
+// each W half (128 columns): acc[ha][hb] = 2 x 2 MFMA tiles of 16x16, 64 accumulator VGPRs.  LDS stage =
+// A (16 KiB: half 0 | half 1) + W0 (16 KiB) + W1 (16 KiB) = 48 KiB, three stages.
+//
+//   phase   fetch segment: LDS reads -> regs   DMA refill issued      vmcnt before its barrier     MFMA segment
+//   PA(t)   A0(t) W0(t) W1(t)                  A(t+2)  [2 DMA/wave]   -                            (A0,W0) (A0,W1)
+//   PB(t)   A1(t)                              W(t+3)  [4 DMA/wave]   vmcnt(10) -> A,W(t+1) landed  (A1,W0) (A1,W1)
+//
+// Stage t%3 is refilled with tile t+3: its W halves as soon as PA(t) has read them (issued in PB(t)), its A
+// once PB(t) has read half 1 (issued in PA(t+1)).  Two K-tiles (96 KiB) are in flight across the barriers.
+// Every phase is [fetch] barrier [16 MFMAs] barrier, waves 4-7 one barrier interval behind waves 0-3.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "hg_gemm_dev.h"
+
+namespace hg {
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int tiles_n, const int n_tiles,
+                                                     const unsigned a_bytes, const int mode) {
+#if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins (buffer resources, LDS DMA): host sees just the stub
+    constexpr int BM = 128, BK = 64;
+    constexpr int AB = 16384, WH = 16384;              // bytes: A tile (both halves), one W half
+    constexpr int STAGE = AB + 2 * WH;                 // 48 KiB
+    constexpr int NST = 3;
+    constexpr int GA = 2, GW = 4;                      // DMA instructions per wave: A tile, both W halves
+    constexpr int NWT = GW + GA + GW;                  // younger DMAs when A,W(t+1) must have landed
+    constexpr bool RESID = (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_SCALE_RESID_F32);
+    constexpr bool F16OUT = (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_BIAS_RELU_F16);
+    constexpr int E = F16OUT ? 8 : 16;                 // epilogue store instructions per wave
+    constexpr int R = RESID ? 16 : 0;                  // residual-row prefetch loads per wave
+    constexpr int BIAS_OFF = NST * STAGE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nk = p.K / BK;
+
+    const int G = gridDim.x, bid = blockIdx.x;
+    const int slot = ((G & 7) == 0) ? (bid & 7) * (G >> 3) + (bid >> 3) : bid;
+    const int my_tiles = (n_tiles - slot + G - 1) / G;
+    if (my_tiles <= 0) return;
+    const int S = my_tiles * nk;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (unsigned)((size_t)p.N * p.K * 2), 0x00020000);
+
+    // ---- DMA source offsets: a piece is 8 rows x 128 B; lane -> (row = l>>3, chunk' = l&7)
+    int voffA[GA], voffW[GW];
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+        const int row = (wave * GA + i) * 8 + (lane >> 3);            // 0..127
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        voffA[i] = row * p.lda * 2 + c * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < GW; ++i) {
+        const int row = (wave * GW + i) * 8 + (lane >> 3);            // 0..255 (W0 = 0..127, W1 = 128..255)
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        voffW[i] = row * p.K * 2 + c * 16;
+    }
+    // ---- two load streams (A and W are issued in different phases)
+    struct Ld { int g, kt, r, soff, st; };
+    Ld lA{-1, nk - 1, -1, 0, 0}, lW{-1, nk - 1, -1, 0, 0};
+    auto advance = [&](Ld& l, bool isA) {
+        ++l.g;
+        if (++l.kt == nk) {
+            l.kt = 0;
+            ++l.r;
+            const int id = slot + l.r * G;
+            const int tm = id / tiles_n, tn = id - tm * tiles_n;
+            l.soff = isA ? tm * BM * p.lda * 2 : tn * 256 * p.K * 2;
+        }
+        l.st = (l.g % NST) * STAGE;
+    };
+    auto issue_A = [&]() {
+        advance(lA, true);
+#pragma unroll
+        for (int i = 0; i < GA; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (HG_LDS void*)(smem + lA.st + (wave * GA + i) * 1024), 16,
+                                                     voffA[i], lA.soff + lA.kt * (BK * 2), 0, 0);
+    };
+    auto issue_W = [&]() {
+        advance(lW, false);
+#pragma unroll
+        for (int i = 0; i < GW; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (HG_LDS void*)(smem + lW.st + AB + (wave * GW + i) * 1024), 16,
+                                                     voffW[i], lW.soff + lW.kt * (BK * 2), 0, 0);
+    };
+
+    // ---- fragment read offsets (row bases are multiples of 16 -> lane-constant swizzle)
+    const int sw = (lane >> 1) & 7;
+    int coff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) coff[ks] = ((ks * 4 + (lane >> 4)) ^ sw) << 4;
+    const int a_row = (wm * 32 + (lane & 15)) * 128;                 // + ha*8192 + f*2048
+    const int w_row = AB + (wn * 32 + (lane & 15)) * 128;            // + hb*WH + g2*2048
+
+    half8 xa[2][2], wb[2][2][2];
+    auto read_A = [&](int ha, int st) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                xa[f][ks] = *reinterpret_cast<const half8*>(smem + st + ha * 8192 + a_row + f * 2048 + coff[ks]);
+    };
+    auto read_W = [&](int st) {
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    wb[hb][g2][ks] = *reinterpret_cast<const half8*>(smem + st + hb * WH + w_row + g2 * 2048 + coff[ks]);
+    };
+    f32x4 acc[2][2][2][2];
+    auto mma = [&](auto HA) {
+        constexpr int ha = decltype(HA)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int g2 = 0; g2 < 2; ++g2)
+                        acc[ha][hb][f][g2] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[hb][g2][ks], xa[f][ks], acc[ha][hb][f][g2], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    auto sync_fetch = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto sync_mma = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        barrier_raw();
+    };
+
+    // ---- bias -> LDS once per workgroup
+    {
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = tid; i < p.N / 4; i += 512)
+            *reinterpret_cast<f32x4*>(smem + BIAS_OFF + i * 16) = p.bias ? reinterpret_cast<const f32x4*>(p.bias)[i] : z;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    // ---- prologue: W(0) A(0) W(1) A(1) W(2); A(2) is issued by the first PA, W(3) by the first PB
+    issue_W(); issue_A();
+    if (S > 1) { issue_W(); issue_A(); }
+    if (S > 2) issue_W();
+    if (S > 2) wait_vm<NWT>();
+    else if (S > 1) wait_vm<GW + GA>();
+    else wait_vm<0>();
+    barrier_raw();
+    const bool late = (wave >= 4) && !(mode & 8);
+    if (late) barrier_raw();
+
+    int g = 0;
+    for (int r = 0; r < my_tiles; ++r) {
+        const int id = slot + r * G;
+        const int tm = id / tiles_n, tn = id - tm * tiles_n;
+        const int m0 = tm * BM, n0 = tn * 256;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int g2 = 0; g2 < 2; ++g2) acc[a][b][f][g2] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 xres[RESID ? 2 : 1][RESID ? 2 : 1][RESID ? 2 : 1][RESID ? 2 : 1];
+        for (int kt = 0; kt < nk; ++kt, ++g) {
+            const int st = (g % NST) * STAGE;
+            const bool xl = RESID && kt == nk - 1;
+            // ---------------- PA: fetch A0, W0, W1 of this K-tile; refill A(g+2); quadrants (A0,W0) (A0,W1)
+            read_A(0, st);
+            read_W(st);
+            if (g + 2 < S) issue_A();
+            if constexpr (RESID) {
+                if (xl) {      // residual rows of this tile, needed by the epilogue one K-tile later
+#pragma unroll
+                    for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+                        for (int f = 0; f < 2; ++f) {
+                            int m = m0 + ha * 64 + wm * 32 + f * 16 + (lane & 15);
+                            m = m < p.M ? m : p.M - 1;
+#pragma unroll
+                            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                                for (int g2 = 0; g2 < 2; ++g2) {
+                                    const int n = n0 + hb * 128 + wn * 32 + g2 * 16 + 4 * (lane >> 4);
+                                    xres[ha][hb][f][g2] = *reinterpret_cast<const f32x4*>(
+                                        reinterpret_cast<const float*>(p.out) + (size_t)m * p.ldc + n);
+                                }
+                        }
+                }
+            }
+            sync_fetch();
+            mma(I0{});
+            sync_mma();
+            // ---------------- PB: fetch A1; refill W(g+3); wait for A,W(g+1); quadrants (A1,W0) (A1,W1)
+            read_A(1, st);
+            const bool issued = g + 3 < S;
+            if (issued) issue_W();
+            if (g + 1 < S) {
+                if (!issued) wait_vm<0>();
+                else if (xl) wait_vm<NWT + R>();
+                else if (r > 0 && kt == 0) wait_vm<NWT + E>();
+                else wait_vm<NWT>();
+            }
+            sync_fetch();
+            mma(I1{});
+            sync_mma();
+        }
+        // ---------------- epilogue
+        if (mode & 4) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int f = 0; f < 2; ++f)
+#pragma unroll
+                        for (int g2 = 0; g2 < 2; ++g2) asm volatile("" ::"v"(acc[a][b][f][g2]));
+            continue;
+        }
+        const int q = lane >> 4;
+        if constexpr (F16OUT) {
+            half_t* outp = reinterpret_cast<half_t*>(p.out);
+#pragma unroll
+            for (int ha = 0; ha < 2; ++ha) {
+                const int mX = m0 + ha * 64 + wm * 32 + (lane & 15);
+                const int m = mX + ((q & 1) ? 16 : 0);
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                    for (int g2 = 0; g2 < 2; ++g2) {
+                        const int nb = n0 + hb * 128 + wn * 32 + g2 * 16;
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (nb + 4 * q) * 4);
+                        f32x4 vx = acc[ha][hb][0][g2] + bv, vy = acc[ha][hb][1][g2] + bv;
+                        if constexpr (EPI == EPI_BIAS_QGELU_F16) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { vx[e] = quick_gelu_r(vx[e]); vy[e] = quick_gelu_r(vy[e]); }
+                        }
+                        if constexpr (EPI == EPI_BIAS_RELU_F16) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { vx[e] = fmaxf(vx[e], 0.f); vy[e] = fmaxf(vy[e], 0.f); }
+                        }
+                        half4 hx, hy;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { hx[e] = (half_t)vx[e]; hy[e] = (half_t)vy[e]; }
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                        const u32x2 ux = __builtin_bit_cast(u32x2, hx), uy = __builtin_bit_cast(u32x2, hy);
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(ux[0], uy[0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(ux[1], uy[1], false, false);
+                        const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                        if (m < p.M) *reinterpret_cast<u32x4*>(outp + (size_t)m * p.ldc + nb + 4 * (q & ~1)) = o;
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const int m = m0 + ha * 64 + wm * 32 + f * 16 + (lane & 15);
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                        for (int g2 = 0; g2 < 2; ++g2) {
+                            const int n = n0 + hb * 128 + wn * 32 + g2 * 16 + 4 * q;
+                            f32x4 v = acc[ha][hb][f][g2] + *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + n * 4);
+                            if constexpr (RESID) {
+                                if (m < p.M) {
+                                    if constexpr (EPI == EPI_SCALE_RESID_F32) v *= *reinterpret_cast<const f32x4*>(p.pos + n);
+                                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) =
+                                        xres[ha][hb][f][g2] + v;
+                                }
+                            } else {
+                                epilogue_ring<EPI>(p, m, n, v);
+                            }
+                        }
+                }
+        }
+    }
+    if (!late) barrier_raw();   // balances the extra barrier of the late waves
+#endif
+}
+
+template <int EPI>
+static hipError_t launch_ring2_t(const GemmArgs& a, hipStream_t s) {
+    constexpr int RING = 3 * 49152;
+    const int LDS = RING + a.N * 4;
+    if (LDS > 160 * 1024) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    static int n_cu = 256;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring2<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            n_cu = prop.multiProcessorCount;
+        attr_set = true;
+    }
+    const int tiles_m = (a.M + 127) / 128, tiles_n = a.N / 256;
+    const int n_tiles = tiles_m * tiles_n;
+    const int grid = n_tiles < n_cu ? n_tiles : n_cu;
+    const size_t a_bytes = (size_t)tiles_m * 128 * a.lda * 2;
+    static const int mode = []() { const char* e = getenv("HG_RING_MODE"); return e ? atoi(e) : 0; }();
+    hipLaunchKernelGGL((gemm_ring2<EPI>), dim3(grid), dim3(512), LDS, s, a, tiles_n, n_tiles, (unsigned)a_bytes, mode);
+    return hipGetLastError();
+}
+
+// N*4 bytes of bias must fit behind the 144 KiB ring
+bool gemm_ring2_ok(const GemmArgs& a) { return gemm_ring_ok(a) && a.N <= 3072; }
+
+hipError_t launch_gemm_ring2(int epi, const GemmArgs& a, hipStream_t s) {
+    switch (epi) {
+        case EPI_BIAS_F16: return launch_ring2_t<EPI_BIAS_F16>(a, s);
+        case EPI_BIAS_QGELU_F16: return launch_ring2_t<EPI_BIAS_QGELU_F16>(a, s);
+        case EPI_BIAS_RELU_F16: return launch_ring2_t<EPI_BIAS_RELU_F16>(a, s);
+        case EPI_BIAS_RESID_F32: return launch_ring2_t<EPI_BIAS_RESID_F32>(a, s);
+        case EPI_BIAS_F32: return launch_ring2_t<EPI_BIAS_F32>(a, s);
+        case EPI_PATCH_F32: return launch_ring2_t<EPI_PATCH_F32>(a, s);
+        case EPI_BIAS_RELU_F32: return launch_ring2_t<EPI_BIAS_RELU_F32>(a, s);
+        case EPI_SCALE_RESID_F32: return launch_ring2_t<EPI_SCALE_RESID_F32>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace hg

@@ -38,6 +38,8 @@ double gemm_flops(const GemmArgs& a);
 // persistent ring kernel (hg_gemm_ring.hip) and the simple 128x128 kernel (hg_gemm.hip)
 bool gemm_ring_ok(const GemmArgs& a);
 hipError_t launch_gemm_ring(int epi, const GemmArgs& a, hipStream_t s);
+bool gemm_ring2_ok(const GemmArgs& a);
+hipError_t launch_gemm_ring2(int epi, const GemmArgs& a, hipStream_t s);
 hipError_t launch_gemm_simple(int epi, const GemmArgs& a, hipStream_t s);
 
 // ---- attention: softmax(Q K^T / sqrt(64) [+causal]) V, head_dim 64 --------------------------
