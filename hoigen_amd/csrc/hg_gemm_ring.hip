@@ -38,7 +38,7 @@ namespace hg {
 
 template <int MF, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int tiles_n, const int n_tiles,
-                                                    const unsigned a_bytes, const int mode) {
+                                                    const unsigned a_bytes, const int mode, const int gsz) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins (buffer resources, LDS DMA): host sees just the stub
     constexpr int BM = 64 * MF, BK = 64;
     constexpr int AH = MF * 4096, BH = 16384;          // bytes per A / W half-tile slot
@@ -59,9 +59,31 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     const int nk = p.K / BK;
 
     // ---- this workgroup's tile list: round r -> tile id (XCD-contiguous chunks of 32 tiles)
+    // Tile order (L2 locality): the list is n-group-major (groups of `gsz` column tiles whose W slices fit one
+    // XCD's L2 together), m-tile next, column tile inside the group fastest.  XCD x (= blockIdx % 8 under
+    // round-robin placement; speed only) owns the contiguous list range [x*T8, (x+1)*T8) and its CUs walk it
+    // 'cpx' items per round, so an XCD keeps re-using the same W slices while streaming A panels.
     const int G = gridDim.x, bid = blockIdx.x;
-    const int slot = ((G & 7) == 0) ? (bid & 7) * (G >> 3) + (bid >> 3) : bid;
-    const int my_tiles = (n_tiles - slot + G - 1) / G;        // tiles slot, slot+G, ...
+    const bool xcd_ok = (G & 7) == 0;
+    const int cpx = xcd_ok ? (G >> 3) : G;                         // workgroups per XCD
+    const int T8 = xcd_ok ? (n_tiles + 7) / 8 : n_tiles;            // list items per XCD
+    const int xbase = xcd_ok ? (bid & 7) * T8 : 0;
+    const int xend = (xbase + T8 < n_tiles) ? xbase + T8 : n_tiles;
+    const int slot = xbase + (xcd_ok ? (bid >> 3) : bid);          // first list item of this workgroup
+    const int my_tiles = slot < xend ? (xend - slot + cpx - 1) / cpx : 0;
+    const int tiles_m_all = n_tiles / tiles_n;
+    const int ngf = tiles_n / gsz, grem = tiles_n - ngf * gsz, per_grp = tiles_m_all * gsz;
+    auto tile_of = [&](int item, int& tm, int& tn) {
+        if (item < ngf * per_grp) {
+            const int grp = item / per_grp, rr = item - grp * per_grp;
+            tm = rr / gsz;
+            tn = grp * gsz + (rr - tm * gsz);
+        } else {
+            const int rr = item - ngf * per_grp;
+            tm = rr / grem;
+            tn = ngf * gsz + (rr - tm * grem);
+        }
+    };        // tiles slot, slot+G, ...
     if (my_tiles <= 0) return;
     const int S = my_tiles * nk;                               // K-tiles in this workgroup's stream
 
@@ -93,8 +115,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
         if (++ld_kt == nk) {
             ld_kt = 0;
             ++ld_r;
-            const int id = slot + ld_r * G;
-            const int tm = id / tiles_n, tn = id - tm * tiles_n;
+            int tm, tn;
+            tile_of(slot + ld_r * cpx, tm, tn);
             ld_sA = (mode & 1) ? 0 : tm * BM * p.lda * 2;     // mode 1 (timing experiment): every tile reads tile 0
             ld_sW = (mode & 1) ? 0 : tn * 256 * p.K * 2;
         }
@@ -213,8 +235,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
 
     int g = 0;
     for (int r = 0; r < my_tiles; ++r) {
-        const int id = slot + r * G;
-        const int tm = id / tiles_n, tn = id - tm * tiles_n;
+        int tm, tn;
+        tile_of(slot + r * cpx, tm, tn);
         const int m0 = tm * BM, n0 = tn * 256;
         zero_acc();
         f32x4 xres[XPRE ? 2 : 1][XPRE ? 2 : 1][XPRE ? MF : 1][XPRE ? 2 : 1];
@@ -386,7 +408,12 @@ static hipError_t launch_ring_t(const GemmArgs& a, hipStream_t s) {
     const int grid = n_tiles < n_cu ? n_tiles : n_cu;
     const size_t a_bytes = (size_t)tiles_m * BM * a.lda * 2;      // A is allocated with rows padded to 256
     static const int mode = []() { const char* e = getenv("HG_RING_MODE"); return e ? atoi(e) : 0; }();
-    hipLaunchKernelGGL((gemm_ring<MF, EPI>), dim3(grid), dim3(512), LDS, s, a, tiles_n, n_tiles, (unsigned)a_bytes, mode);
+    static const int gsz_env = []() { const char* e = getenv("HG_RING_GSZ"); return e ? atoi(e) : 0; }();
+    // column tiles per L2 group: W slices of one group (gsz * 256 rows * K * 2 B) should fit ~1.5 MiB
+    int gsz = gsz_env > 0 ? gsz_env : (int)((1536 * 1024) / ((size_t)512 * a.K));
+    if (gsz < 1) gsz = 1;
+    if (gsz > tiles_n) gsz = tiles_n;
+    hipLaunchKernelGGL((gemm_ring<MF, EPI>), dim3(grid), dim3(512), LDS, s, a, tiles_n, n_tiles, (unsigned)a_bytes, mode, gsz);
     return hipGetLastError();
 }
 
