@@ -316,3 +316,41 @@ def test_text_truncation_is_exact_selection(fullA, g0):
     fullA.truncate_text = True
     whole, worst = rel_l2(a, b.cpu().numpy())
     assert worst <= 2e-4, "running the causal tower on max(EOT)+1 positions must not change the EOT outputs"
+
+
+def test_generation_pipeline_vs_oracle(g0):
+    """z -> Generator -> PromptLearner -> TextEncoder -> L2 -> mlp_net, two branches in one
+    text-tower pass, against the CPU oracle chain on the same latents."""
+    from oracle import clip_oracle as co, vae_oracle as vo
+    from hoigen_amd.generation import Branch, FeatureSampler
+    d = dev()
+    sd_np = synth.clip_state_dict(synth.VIT_B16, 0)
+    m = build_model(synth.to_torch(sd_np)).float().to(d)
+    sd = co.reference_weight_rounding(sd_np)
+    names = {"hoi": g0["_classnames"]["hoi"], "obj": g0["_classnames"]["obj"]}
+    cls = {"hoi": vae.PromptLearner_hoi, "obj": vae.PromptLearner_o}
+    tgt = {"hoi": torch.tensor([(41 * i + 3) % 600 for i in range(12)]), "obj": torch.tensor([(9 * i + 1) % 80 for i in range(8)])}
+    branches, ref = {}, {}
+    for i, k in enumerate(("hoi", "obj")):
+        gw, mw = synth.generator_state_dict(70 + i), synth.mlp_net_state_dict(80 + i)
+        G_, M_ = vae.Generator().to(d), vae.mlp_net(512, 512, 512).to(d)
+        G_.load_state_dict(synth.to_torch(gw)); M_.load_state_dict(synth.to_torch(mw))
+        pl = cls[k](names[k], m).float().to(d)
+        ctx = synth.hg_normal((pl.n_ctx, 512), 90 + i, 0.02)
+        with torch.no_grad():
+            pl.ctx.copy_(torch.from_numpy(ctx))
+        branches[k] = Branch(G_, pl, M_, tgt[k])
+        ref[k] = (co.as_tensors(gw), co.as_tensors(mw), torch.from_numpy(ctx), pl.tokenized_prompts.cpu(), pl.n_ctx)
+    sampler = FeatureSampler(m, branches)
+    z = {k: torch.from_numpy(synth.hg_normal((len(tgt[k]), 512), 95 + i)) for i, k in enumerate(("hoi", "obj"))}
+    got = sampler.step({k: v.to(d) for k, v in z.items()})
+    for k in ("hoi", "obj"):
+        gw, mw, ctx, tok, n_ctx = ref[k]
+        bias = vo.generator(gw, z[k])
+        emb = sd["token_embedding.weight"][tok]
+        prompts = vo.assemble_prompts(emb[:, :1], emb[:, 1 + n_ctx:], ctx, bias, tgt[k])
+        t = co.l2_normalize(co.text_encoder_embeds(sd, prompts, tok[tgt[k]]))
+        check(got[k], vo.mlp_net(mw, t).numpy(), what=f"generation pipeline branch {k}")
+    feat, target = sampler.sample(iterations=2)
+    assert feat.shape == (2 * 20, 512) and target.shape == (40,) and torch.isfinite(feat).all()
+    assert torch.equal(target.cpu(), torch.cat([tgt["hoi"].repeat(2), tgt["obj"].repeat(2)]))
