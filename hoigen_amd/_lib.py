@@ -13,7 +13,8 @@ import threading
 from typing import Dict, Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libhoigen_amd.so")
+# HG_LIB_PATH: load another build of the same ABI (A/B timing of kernel variants inside one GPU session)
+LIB_PATH = os.environ.get("HG_LIB_PATH") or os.path.join(HERE, "csrc", "libhoigen_amd.so")
 HG_MAX_SLOTS = 4
 HG_F32, HG_F16 = 0, 1
 
@@ -110,7 +111,7 @@ SIGNATURES = {
 }
 
 _lib = None
-_lock = threading.Lock()
+_lock = threading.RLock()   # re-entrant: ctx() calls lib() under the lock
 _ctxs: Dict[int, int] = {}
 
 

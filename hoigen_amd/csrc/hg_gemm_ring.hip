@@ -28,6 +28,7 @@
 //
 // The MFMA is issued with W rows as the A operand and activation rows as the B operand, so a lane
 // holds 4 consecutive output columns of one row: 8-byte (fp16) / 16-byte (fp32) epilogue accesses.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -35,6 +36,20 @@
 #include "hg_gemm_dev.h"
 
 namespace hg {
+
+// Diagnostic build (HG_EXTRA_FLAGS="-DHG_STAMPS -DHG_STAMP_MASK=<bits>"): per-wave s_memtime totals of the
+// selected segment kinds (0 vmcnt waits, 1 lgkmcnt waits, 2 fetch barriers, 3 MFMA segments, 4 MFMA barriers,
+// 5 DMA issue, 6 ds_read issue, 7 epilogue) and of the whole tile loop, written to GemmArgs::dbg.
+#ifdef HG_STAMPS
+#ifndef HG_STAMP_MASK
+#define HG_STAMP_MASK 0xFF
+#endif
+#define SEG_B(k) do { if constexpr ((HG_STAMP_MASK >> (k)) & 1) t_beg = __builtin_amdgcn_s_memtime(); } while (0)
+#define SEG_E(k) do { if constexpr ((HG_STAMP_MASK >> (k)) & 1) tacc[k] += __builtin_amdgcn_s_memtime() - t_beg; } while (0)
+#else
+#define SEG_B(k) do {} while (0)
+#define SEG_E(k) do {} while (0)
+#endif
 
 template <int MF, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int tiles_n, const int n_tiles,
@@ -44,6 +59,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     constexpr int AH = MF * 4096, BH = 16384;          // bytes per A / W half-tile slot
     constexpr int STAGE = 2 * AH + 2 * BH;
     constexpr int GA = MF / 2, GB = 2;
+    static_assert(GA <= 2, "DMA piece helpers cover two pieces per half-tile");
     constexpr int N1 = 2 * GA + 3 * GB, N2 = 3 * GA + 2 * GB;
     constexpr int E = 8 * MF;                          // epilogue store instructions per wave
     constexpr bool RESID = (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_SCALE_RESID_F32);
@@ -52,6 +68,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     constexpr int R = XPRE ? E : 0;                    // x prefetch loads per wave
     constexpr int BIAS_OFF = 2 * STAGE;                // bias[N] staged in LDS behind the ring
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef HG_STAMPS
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_beg = 0, t_all = 0;
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -85,6 +104,20 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
         }
     };        // tiles slot, slot+G, ...
     if (my_tiles <= 0) return;
+    // De-synchronised epilogues: all tiles take the same time, so every CU would store (and, for the residual
+    // epilogue, load) its output tile at the same moment - HBM idles during the K loops and saturates during
+    // the epilogues.  Workgroups that own one tile fewer than the fullest ones have a tile time of slack; they
+    // spend a pseudo-random fraction of it BEFORE their first tile instead of after their last.
+    {
+        const int dunit = mode >> 8;                               // estimated cycles per K-tile, 0 = off
+        const int max_tiles = (T8 + cpx - 1) / cpx;
+        if (dunit > 0 && my_tiles < max_tiles) {
+            const unsigned h = ((unsigned)bid * 2654435761u) >> 24;   // 0..255
+            const long long d = ((long long)(max_tiles - my_tiles) * nk * dunit * h) >> 8;
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            while ((long long)(__builtin_amdgcn_s_memtime() - t0) < d) __builtin_amdgcn_s_sleep(32);
+        }
+    }
     const int S = my_tiles * nk;                               // K-tiles in this workgroup's stream
 
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
@@ -99,13 +132,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
         for (int i = 0; i < GA; ++i) {
             const int row = (wave * GA + i) * 8 + (lane >> 3);
             const int c = (lane & 7) ^ ((row >> 1) & 7);
-            voffA[h][i] = (h * (BM / 2) + row) * p.lda * 2 + c * 16;
+            voffA[h][i] = (h * (BM / 2) + row) * p.lda * 2 + c * 16 - i * 1024;
         }
 #pragma unroll
         for (int i = 0; i < GB; ++i) {
             const int row = (wave * GB + i) * 8 + (lane >> 3);
             const int c = (lane & 7) ^ ((row >> 1) & 7);
-            voffW[h][i] = (h * 128 + row) * p.K * 2 + c * 16;
+            voffW[h][i] = (h * 128 + row) * p.K * 2 + c * 16 - i * 1024;
         }
     }
     // ---- load-stream state (wave-uniform): position ld_g, its tile origin and K offset
@@ -122,18 +155,31 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
         }
         ld_buf = (ld_g & 1) * STAGE;
     };
-    auto issue_A = [&](int h) {
-#pragma unroll
-        for (int i = 0; i < GA; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (HG_LDS void*)(smem + ld_buf + h * AH + (wave * GA + i) * 1024),
-                                                     16, voffA[h][i], ld_sA + ld_kt * (BK * 2), 0, 0);
+    // pieces [i0, i1) of a half-tile (interleaving the pieces with the segment's LDS reads was measured: no
+    // gain).  All pieces of a half-tile share one M0 (LDS base): piece i adds its
+    // 1 KiB through the instruction's immediate offset, which the hardware also adds to the global address,
+    // so voff*[h][i] carry -1024 * i
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    auto dma_A = [&](int h, auto I) {
+        constexpr int i = decltype(I)::value;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (HG_LDS void*)(smem + ld_buf + h * AH + wave * GA * 1024), 16,
+                                                 voffA[h][i], ld_sA + ld_kt * (BK * 2), i * 1024, 0);
     };
-    auto issue_W = [&](int h) {
-#pragma unroll
-        for (int i = 0; i < GB; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                rsW, (HG_LDS void*)(smem + ld_buf + 2 * AH + h * BH + (wave * GB + i) * 1024), 16, voffW[h][i],
-                ld_sW + ld_kt * (BK * 2), 0, 0);
+    auto dma_W = [&](int h, auto I) {
+        constexpr int i = decltype(I)::value;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (HG_LDS void*)(smem + ld_buf + 2 * AH + h * BH + wave * GB * 1024),
+                                                 16, voffW[h][i], ld_sW + ld_kt * (BK * 2), i * 1024, 0);
+    };
+    auto issue_A = [&](int h, int i0, int i1) {
+        if (i0 <= 0 && 0 < i1) dma_A(h, P0{});
+        if constexpr (GA > 1) {
+            if (i0 <= 1 && 1 < i1) dma_A(h, P1{});
+        }
+    };
+    auto issue_W = [&](int h, int i0, int i1) {
+        if (i0 <= 0 && 0 < i1) dma_W(h, P0{});
+        if (i0 <= 1 && 1 < i1) dma_W(h, P1{});
     };
 
     // ---- fragment read offsets
@@ -185,6 +231,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             }
             return;
         }
+        SEG_B(3);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -195,18 +242,28 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                     acc[ha][hb][f][g2] =
                         __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[hb][g2][ks], xa[f][ks], acc[ha][hb][f][g2], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
+        SEG_E(3);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     // end of a fetch segment: this wave's fragment reads are complete, then the workgroup barrier; the
     // sched_barrier keeps the compiler from hoisting the (register-only) MFMAs into the fetch segment
     auto sync_fetch = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // the builtin (not inline asm) so that the compiler's waitcnt pass knows the LDS reads have returned:
+        // with an opaque asm it keeps them on its scoreboard and throttles the next segment's ds_reads
+        SEG_B(1);
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+        SEG_E(1);
+        SEG_B(2);
+        barrier_raw();
+        SEG_E(2);
         __builtin_amdgcn_sched_barrier(0);
     };
     auto sync_mma = [&]() {
         __builtin_amdgcn_sched_barrier(0);
+        SEG_B(4);
         barrier_raw();
+        SEG_E(4);
     };
 
     // ---- bias -> LDS once per workgroup (epilogue reads must not touch vmcnt: a register-returning
@@ -219,10 +276,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     }
     // ---- prologue: stream positions 0 and 1 (A1 of position 1 is issued in the first P1)
     ld_advance();
-    issue_A(0); issue_W(0); issue_W(1); issue_A(1);
+    issue_A(0, 0, GA); issue_W(0, 0, GB); issue_W(1, 0, GB); issue_A(1, 0, GA);
     if (S > 1) {
         ld_advance();
-        issue_A(0); issue_W(0); issue_W(1);
+        issue_A(0, 0, GA); issue_W(0, 0, GB); issue_W(1, 0, GB);
         wait_vm<N1>();                     // A0, W0 of position 0 landed
     } else {
         wait_vm<GA + GB>();
@@ -233,6 +290,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     const bool late = (wave >= 4) && !(mode & 8);
     if (late) barrier_raw();
 
+#ifdef HG_STAMPS
+    t_all = __builtin_amdgcn_s_memtime();
+#endif
     int g = 0;
     for (int r = 0; r < my_tiles; ++r) {
         int tm, tn;
@@ -248,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             // ---------------- P1: fetch A0(t), W0(t); refill A1(t+1); then quadrant (0,0)
             read_A(0, buf);
             read_W(I0{}, buf);
-            if (g + 1 < S) issue_A(1);            // A1 of position g+1 (ld state already at g+1)
+            if (g + 1 < S) issue_A(1, 0, GA);     // A1 of position g+1 (ld state already at g+1)
             if constexpr (XPRE) {
                 if (xl) {
 #pragma unroll
@@ -268,40 +328,47 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                         }
                 }
             }
+            SEG_B(0);
             if (!more) wait_vm<0>();              // -> W1(t) landed (read in P2)
             else if (xl) wait_vm<N2 + R>();
             else if (post && kt <= 1) wait_vm<N2 + E>();
             else wait_vm<N2>();
+            SEG_E(0);
             sync_fetch();
             mma(I0{}, I0{});
             sync_mma();
             // ---------------- P2: fetch W1(t); slot A0(t) is free -> A0(t+2); quadrant (0,1)
             read_W(I1{}, buf);
-            if (more) { ld_advance(); issue_A(0); }
+            if (more) { ld_advance(); issue_A(0, 0, GA); }
+            SEG_B(0);
             if (!more) wait_vm<0>();              // -> A1(t) landed (read in P3)
             else if (xl) wait_vm<N2 + R>();
             else if (post && kt == 0) wait_vm<N2 + E>();
             else wait_vm<N2>();
+            SEG_E(0);
             sync_fetch();
             mma(I0{}, I1{});
             sync_mma();
             // ---------------- P3: fetch A1(t); slot W0(t) free -> W0(t+2); quadrant (1,1)
             read_A(1, buf);
-            if (more) issue_W(0);
+            if (more) issue_W(0, 0, GB);
             sync_fetch();
             mma(I1{}, I1{});
             sync_mma();
             // ---------------- P4: slot W1(t) free -> W1(t+2); quadrant (1,0)
-            if (more) issue_W(1);
+            if (more) issue_W(1, 0, GB);
+            SEG_B(0);
             if (!more) wait_vm<0>();              // -> A0(t+1), W0(t+1) landed (read in the next P1)
             else if (xl) wait_vm<N1 + R>();
             else if (post && kt == 0) wait_vm<N1 + E>();
             else wait_vm<N1>();
+            SEG_E(0);
             sync_fetch();
             mma(I1{}, I0{});
             sync_mma();
         }
         // ---------------- epilogue of tile r (the ring keeps prefetching the next tile meanwhile)
+        SEG_B(7);
         if (mode & 4) {   // timing experiment: no epilogue
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -351,6 +418,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                             const auto s1 = __builtin_amdgcn_permlane16_swap(ux[1], uy[1], false, false);
                             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                             const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                            if (mode & 16) {   // timing experiment: lane-linear (fully coalesced, WRONG) addresses
+                                const int idx = ((ha * (MF / 2) + f / 2) * 2 + hb) * 2 + g2;
+                                const int rr = m0 + (wave * (4 * MF) + idx) * 2 + (lane >> 5);
+                                if (rr < p.M) *reinterpret_cast<u32x4*>(outp + (size_t)rr * p.ldc + n0 + (lane & 31) * 8) = o;
+                            } else
                             if (m < p.M)
                                 *reinterpret_cast<u32x4*>(outp + (size_t)m * p.ldc + nb + 4 * (q & ~1)) = o;
                         }
@@ -380,7 +452,17 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                     }
             }
         }
+        SEG_E(7);
     }
+#ifdef HG_STAMPS
+    if (p.dbg && lane == 0) {
+        unsigned long long* d = p.dbg + (size_t)(blockIdx.x * 8 + wave) * 16;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = tacc[k];
+        d[8] = __builtin_amdgcn_s_memtime() - t_all;
+        d[9] = (unsigned long long)my_tiles * nk;
+    }
+#endif
     if (!late) barrier_raw();   // balances the extra barrier of the late waves
 #endif
 }
@@ -407,12 +489,47 @@ static hipError_t launch_ring_t(const GemmArgs& a, hipStream_t s) {
     const int n_tiles = tiles_m * tiles_n;
     const int grid = n_tiles < n_cu ? n_tiles : n_cu;
     const size_t a_bytes = (size_t)tiles_m * BM * a.lda * 2;      // A is allocated with rows padded to 256
-    static const int mode = []() { const char* e = getenv("HG_RING_MODE"); return e ? atoi(e) : 0; }();
+    static const int mode = []() {
+        const char* e = getenv("HG_RING_MODE");
+        // start stagger: estimated cycles per K-tile (a deliberate under-estimate; HG_RING_DELAY=0 turns it off)
+        const char* d = getenv("HG_RING_DELAY");
+        return (e ? atoi(e) & 0xFF : 0) | ((d ? atoi(d) : (MF == 4 ? 3000 : 1800)) << 8);
+    }();
     static const int gsz_env = []() { const char* e = getenv("HG_RING_GSZ"); return e ? atoi(e) : 0; }();
-    // column tiles per L2 group: W slices of one group (gsz * 256 rows * K * 2 B) should fit ~1.5 MiB
+    // column tiles per L2 group: W slices of one group (gsz * 256 rows * K * 2 B) should fit ~1.5 MiB, but
+    // never fewer than 3: an A panel that is not shared by neighbouring column tiles is re-read from HBM once
+    // per column tile (c_proj, K = 3072: 310 MB of activations x 3)
     int gsz = gsz_env > 0 ? gsz_env : (int)((1536 * 1024) / ((size_t)512 * a.K));
-    if (gsz < 1) gsz = 1;
+    if (gsz < 3) gsz = 3;
     if (gsz > tiles_n) gsz = tiles_n;
+#ifdef HG_STAMPS
+    if (getenv("HG_STAMPS")) {
+        const size_t n = (size_t)grid * 8 * 16;
+        unsigned long long* d = nullptr;
+        if (hipMalloc(&d, n * 8) != hipSuccess) return hipErrorOutOfMemory;
+        hipMemsetAsync(d, 0, n * 8, s);
+        GemmArgs b = a;
+        b.dbg = d;
+        hipLaunchKernelGGL((gemm_ring<MF, EPI>), dim3(grid), dim3(512), LDS, s, b, tiles_n, n_tiles, (unsigned)a_bytes, mode, gsz);
+        hipStreamSynchronize(s);
+        unsigned long long* h = (unsigned long long*)malloc(n * 8);
+        hipMemcpy(h, d, n * 8, hipMemcpyDeviceToHost);
+        static const char* names[8] = {"vmcnt", "lgkmcnt", "fetch-barrier", "MFMA", "mfma-barrier", "DMA-issue", "ds_read-issue", "epilogue"};
+        for (int w = 0; w < 8; w += 4) {
+            double acc[10] = {0};
+            for (int blk = 0; blk < grid; ++blk)
+                for (int k = 0; k < 10; ++k) acc[k] += (double)h[(size_t)(blk * 8 + w) * 16 + k];
+            const double kts = acc[9] > 0 ? acc[9] : 1;
+            fprintf(stderr, "[stamps] ring<%d,%d> N=%d K=%d wave %d: loop %.0f cycles/K-tile;", MF, EPI, a.N, a.K, w, acc[8] / kts);
+            for (int k = 0; k < 8; ++k)
+                if ((HG_STAMP_MASK >> k) & 1) fprintf(stderr, " %s %.0f", names[k], acc[k] / kts);
+            fprintf(stderr, "\n");
+        }
+        free(h);
+        hipFree(d);
+        return hipGetLastError();
+    }
+#endif
     hipLaunchKernelGGL((gemm_ring<MF, EPI>), dim3(grid), dim3(512), LDS, s, a, tiles_n, n_tiles, (unsigned)a_bytes, mode, gsz);
     return hipGetLastError();
 }

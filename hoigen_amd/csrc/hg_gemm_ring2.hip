@@ -73,6 +73,20 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
         }
     };
     if (my_tiles <= 0) return;
+    // De-synchronised epilogues: all tiles take the same time, so every CU would store (and, for the residual
+    // epilogue, load) its output tile at the same moment - HBM idles during the K loops and saturates during
+    // the epilogues.  Workgroups that own one tile fewer than the fullest ones have a tile time of slack; they
+    // spend a pseudo-random fraction of it BEFORE their first tile instead of after their last.
+    {
+        const int dunit = mode >> 8;                               // estimated cycles per K-tile, 0 = off
+        const int max_tiles = (T8 + cpx - 1) / cpx;
+        if (dunit > 0 && my_tiles < max_tiles) {
+            const unsigned h = ((unsigned)bid * 2654435761u) >> 24;   // 0..255
+            const long long d = ((long long)(max_tiles - my_tiles) * nk * dunit * h) >> 8;
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            while ((long long)(__builtin_amdgcn_s_memtime() - t0) < d) __builtin_amdgcn_s_sleep(32);
+        }
+    }
     const int S = my_tiles * nk;
 
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
@@ -166,7 +180,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     auto sync_fetch = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0); the builtin keeps the compiler's waitcnt scoreboard in sync
+        barrier_raw();
         __builtin_amdgcn_sched_barrier(0);
     };
     auto sync_mma = [&]() {
@@ -226,6 +241,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
 #pragma unroll
                                 for (int g2 = 0; g2 < 2; ++g2) {
                                     const int n = n0 + hb * 128 + wn * 32 + g2 * 16 + 4 * (lane >> 4);
+                                    if (mode & 16) {
+                                        const int idx = ((ha * 2 + f) * 2 + hb) * 2 + g2;
+                                        int rr = m0 + wave * 16 + idx;
+                                        rr = rr < p.M ? rr : p.M - 1;
+                                        xres[ha][hb][f][g2] = *reinterpret_cast<const f32x4*>(
+                                            reinterpret_cast<const float*>(p.out) + (size_t)rr * p.ldc + n0 + lane * 4);
+                                    } else
                                     xres[ha][hb][f][g2] = *reinterpret_cast<const f32x4*>(
                                         reinterpret_cast<const float*>(p.out) + (size_t)m * p.ldc + n);
                                 }
@@ -308,6 +330,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                             const int n = n0 + hb * 128 + wn * 32 + g2 * 16 + 4 * q;
                             f32x4 v = acc[ha][hb][f][g2] + *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + n * 4);
                             if constexpr (RESID) {
+                                if (mode & 16) {
+                                    const int idx = ((ha * 2 + f) * 2 + hb) * 2 + g2;
+                                    const int rr = m0 + wave * 16 + idx;
+                                    if (rr < p.M)
+                                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)rr * p.ldc + n0 + lane * 4) =
+                                            xres[ha][hb][f][g2] + v;
+                                } else
                                 if (m < p.M) {
                                     if constexpr (EPI == EPI_SCALE_RESID_F32) v *= *reinterpret_cast<const f32x4*>(p.pos + n);
                                     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) =
@@ -345,11 +374,18 @@ static hipError_t launch_ring2_t(const GemmArgs& a, hipStream_t s) {
     const int n_tiles = tiles_m * tiles_n;
     const int grid = n_tiles < n_cu ? n_tiles : n_cu;
     const size_t a_bytes = (size_t)tiles_m * 128 * a.lda * 2;
-    static const int mode = []() { const char* e = getenv("HG_RING_MODE"); return e ? atoi(e) : 0; }();
+    static const int mode = []() {
+        const char* e = getenv("HG_RING_MODE");
+        // start stagger: estimated cycles per K-tile (a deliberate under-estimate; HG_RING_DELAY=0 turns it off)
+        const char* d = getenv("HG_RING_DELAY");
+        return (e ? atoi(e) & 0xFF : 0) | ((d ? atoi(d) : 2200) << 8);
+    }();
     static const int gsz_env = []() { const char* e = getenv("HG_RING_GSZ"); return e ? atoi(e) : 0; }();
-    // column tiles per L2 group: W slices of one group (gsz * 256 rows * K * 2 B) should fit ~1.5 MiB
+    // column tiles per L2 group: W slices of one group (gsz * 256 rows * K * 2 B) should fit ~1.5 MiB, but
+    // never fewer than 3: an A panel that is not shared by neighbouring column tiles is re-read from HBM once
+    // per column tile (c_proj, K = 3072: 310 MB of activations x 3)
     int gsz = gsz_env > 0 ? gsz_env : (int)((1536 * 1024) / ((size_t)512 * a.K));
-    if (gsz < 1) gsz = 1;
+    if (gsz < 3) gsz = 3;
     if (gsz > tiles_n) gsz = tiles_n;
     hipLaunchKernelGGL((gemm_ring2<EPI>), dim3(grid), dim3(512), LDS, s, a, tiles_n, n_tiles, (unsigned)a_bytes, mode, gsz);
     return hipGetLastError();

@@ -28,6 +28,7 @@ struct GemmArgs {
     int lda, ldc;
     int M, N, K;
     int G, L;          // EPI_PATCH: patches per image, tokens per image
+    unsigned long long* dbg = nullptr;   // diagnostics: s_memtime stamps (HG_STAMPS=1), normally null
 };
 
 // Requirements: N % 128 == 0, K % 64 == 0, A readable for rows < M, 16-byte aligned rows.

@@ -101,6 +101,18 @@ def test_fails_loudly_without_gpu():
     assert _lib.lib().hg_create(0) is None
 
 
+def test_ctx_before_lib_does_not_deadlock():
+    """ctx() takes the module lock and then calls lib(): the lock must be re-entrant (regression)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from hoigen_amd import _lib\n"
+            "try:\n    _lib.ctx(0); print('ctx ok')\n"
+            "except RuntimeError as e:\n    print('raised')\n") % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and ("raised" in r.stdout or "ctx ok" in r.stdout), r.stderr[-500:]
+
+
 def test_load_error_behaviour(tmp_path):
     with pytest.raises(RuntimeError, match="not found"):
         clip.load("no-such-model")                          # clipnet/clip.py:120
