@@ -49,8 +49,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     constexpr bool RESID = (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_SCALE_RESID_F32);
     // RESID at MF = 2: the residual rows are fetched one K-tile before the epilogue (64 spare VGPRs)
     constexpr bool XPRE = RESID && MF == 2;
-    constexpr int R = XPRE ? E : 0;                    // x prefetch loads per wave
-    constexpr int BIAS_OFF = 2 * STAGE;                // bias[N] staged in LDS behind the ring
+    // folded LayerNorm (EPI_LN_*): (mean, rstd) of this lane's 2*MF rows are fetched one K-tile ahead as well
+    constexpr bool LNC = (EPI == EPI_LN_BIAS_F16 || EPI == EPI_LN_BIAS_QGELU_F16);
+    constexpr int R = XPRE ? E : (LNC ? 2 * MF : 0);   // prefetch loads per wave in the last K-tile
+    constexpr int BIAS_OFF = 2 * STAGE;                // bias[N] (and cs[N] for EPI_LN_*) staged in LDS behind the ring
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -213,8 +215,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     // global load would wait for every older DMA of the ring)
     {
         const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int i = tid; i < p.N / 4; i += 512)
+        for (int i = tid; i < p.N / 4; i += 512) {
             *reinterpret_cast<f32x4*>(smem + BIAS_OFF + i * 16) = p.bias ? reinterpret_cast<const f32x4*>(p.bias)[i] : z;
+            if constexpr (LNC)
+                *reinterpret_cast<f32x4*>(smem + BIAS_OFF + p.N * 4 + i * 16) = reinterpret_cast<const f32x4*>(p.cs)[i];
+        }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
     // ---- prologue: stream positions 0 and 1 (A1 of position 1 is issued in the first P1)
@@ -240,15 +245,29 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
         const int m0 = tm * BM, n0 = tn * 256;
         zero_acc();
         f32x4 xres[XPRE ? 2 : 1][XPRE ? 2 : 1][XPRE ? MF : 1][XPRE ? 2 : 1];
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 mrv[LNC ? 2 : 1][LNC ? MF : 1];
         for (int kt = 0; kt < nk; ++kt, ++g) {
             const int buf = (g & 1) * STAGE;
             const bool more = g + 2 < S;          // a K-tile two positions ahead exists
             const bool post = r > 0;               // epilogue stores of the previous tile may still be pending
-            const bool xl = XPRE && kt == nk - 1;  // residual rows are fetched during the last K-tile
+            const bool xl = (XPRE || LNC) && kt == nk - 1;  // residual rows / row statistics are fetched during the last K-tile
             // ---------------- P1: fetch A0(t), W0(t); refill A1(t+1); then quadrant (0,0)
             read_A(0, buf);
             read_W(I0{}, buf);
             if (g + 1 < S) issue_A(1);            // A1 of position g+1 (ld state already at g+1)
+            if constexpr (LNC) {
+                if (xl) {
+#pragma unroll
+                    for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+                        for (int f = 0; f < MF; ++f) {
+                            int m = m0 + ha * (BM / 2) + wm * MF * 16 + f * 16 + (lane & 15);
+                            m = m < p.M ? m : p.M - 1;
+                            mrv[ha][f] = *reinterpret_cast<const f32x2*>(p.mr + 2 * (size_t)m);
+                        }
+                }
+            }
             if constexpr (XPRE) {
                 if (xl) {
 #pragma unroll
@@ -313,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                         for (int g2 = 0; g2 < 2; ++g2) asm volatile("" ::"v"(acc[a][b][f][g2]));
             continue;
         }
-        constexpr bool F16OUT = (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_BIAS_RELU_F16);
+        constexpr bool F16OUT = (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_BIAS_RELU_F16 || LNC);
         if constexpr (F16OUT) {
             // fp16 outputs: a lane holds 4 consecutive columns (8 B) of one row.  v_permlane16_swap pairs the
             // accumulator tiles f, f+1 (same columns, rows 16 apart) so that even 16-lane groups end up with 8
@@ -333,8 +352,16 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                         for (int g2 = 0; g2 < 2; ++g2) {
                             const int nb = n0 + hb * 128 + wn * 32 + g2 * 16;
                             const f32x4 bv = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (nb + 4 * q) * 4);
-                            f32x4 vx = acc[ha][hb][f][g2] + bv, vy = acc[ha][hb][f + 1][g2] + bv;
-                            if constexpr (EPI == EPI_BIAS_QGELU_F16) {
+                            f32x4 vx, vy;
+                            if constexpr (LNC) {   // rstd * (acc - mean * cs) + bias'
+                                const f32x4 cv = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + p.N * 4 + (nb + 4 * q) * 4);
+                                vx = (acc[ha][hb][f][g2] - cv * mrv[ha][f][0]) * mrv[ha][f][1] + bv;
+                                vy = (acc[ha][hb][f + 1][g2] - cv * mrv[ha][f + 1][0]) * mrv[ha][f + 1][1] + bv;
+                            } else {
+                                vx = acc[ha][hb][f][g2] + bv;
+                                vy = acc[ha][hb][f + 1][g2] + bv;
+                            }
+                            if constexpr (EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_LN_BIAS_QGELU_F16) {
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) { vx[r] = quick_gelu_r(vx[r]); vy[r] = quick_gelu_r(vy[r]); }
                             }
@@ -389,7 +416,8 @@ template <int MF, int EPI>
 static hipError_t launch_ring_t(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = 64 * MF;
     constexpr int RING = 2 * (2 * MF * 4096 + 2 * 16384);
-    const int LDS = RING + a.N * 4;                               // ring + bias[N]
+    constexpr bool LNC = (EPI == EPI_LN_BIAS_F16 || EPI == EPI_LN_BIAS_QGELU_F16);
+    const int LDS = RING + a.N * 4 * (LNC ? 2 : 1);              // ring + bias[N] (+ cs[N])
     if (LDS > 160 * 1024) return hipErrorInvalidValue;
     static bool attr_set = false;
     static int n_cu = 256;
@@ -445,6 +473,8 @@ hipError_t launch_gemm_ring(int epi, const GemmArgs& a, hipStream_t s) {
         HG_RING(EPI_PATCH_F32);
         HG_RING(EPI_BIAS_RELU_F32);
         HG_RING(EPI_SCALE_RESID_F32);
+        HG_RING(EPI_LN_BIAS_F16);
+        HG_RING(EPI_LN_BIAS_QGELU_F16);
         default: return hipErrorInvalidValue;
     }
 #undef HG_RING
