@@ -11,6 +11,7 @@
 //   biases, LN affine, embeddings, positional: fp32
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -31,6 +32,10 @@ struct Buf {
 struct BlockW {
     half_t *w_qkv, *w_out, *w_fc, *w_proj;
     float *b_qkv, *b_out, *b_fc, *b_proj, *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+    // LayerNorm folded into the consuming GEMM: W' = fp16(W * gamma), cs[n] = sum_k W'[n][k],
+    // b' = b + W beta;  LN(x) W^T + b = rstd * (x16 W'^T - mean * cs) + b'
+    half_t *wf_qkv, *wf_fc;
+    float *cs_qkv, *bf_qkv, *cs_fc, *bf_fc;
 };
 
 struct AdapterW {
@@ -91,7 +96,7 @@ struct hg_ctx {
     Vae vae[HG_MAX_SLOTS];
     Mlp mlp[HG_MAX_SLOTS];
     // workspace (grow-only)
-    Buf x, h, qkv, att, fc, head16, tok32, small, i32, ad32, ad16, adkv;
+    Buf x, h, qkv, att, fc, head16, tok32, small, i32, ad32, ad16, adkv, mr, stats;
     int max_chunk_img = 256;
     int max_chunk_txt = 640;
     int max_chunk_rows = 32768;
@@ -210,7 +215,7 @@ int as_f32_T(hg_ctx* c, std::vector<void*>& owned, const hg_tensor& t, int rows,
 }
 
 int load_blocks(hg_ctx* c, std::vector<void*>& owned, const hg_block_weights* src, int layers, int D,
-                std::vector<BlockW>& dst) {
+                std::vector<BlockW>& dst, bool fold_ln) {
     if (!src) return fail(c, HG_ERR_INVALID, "blocks == NULL");
     dst.assign(layers, BlockW{});
     for (int i = 0; i < layers; ++i) {
@@ -230,6 +235,16 @@ int load_blocks(hg_ctx* c, std::vector<void*>& owned, const hg_block_weights* sr
         rc |= as_f32(c, owned, s.ln_2_weight, D, &b.ln2_w, "ln_2.weight");
         rc |= as_f32(c, owned, s.ln_2_bias, D, &b.ln2_b, "ln_2.bias");
         if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
+        if (!fold_ln) continue;
+        rc |= dev_alloc(c, owned, (size_t)3 * D * D * 2, (void**)&b.wf_qkv);
+        rc |= dev_alloc(c, owned, (size_t)3 * D * 4, (void**)&b.cs_qkv);
+        rc |= dev_alloc(c, owned, (size_t)3 * D * 4, (void**)&b.bf_qkv);
+        rc |= dev_alloc(c, owned, (size_t)4 * D * D * 2, (void**)&b.wf_fc);
+        rc |= dev_alloc(c, owned, (size_t)4 * D * 4, (void**)&b.cs_fc);
+        rc |= dev_alloc(c, owned, (size_t)4 * D * 4, (void**)&b.bf_fc);
+        if (rc) return rc < 0 ? rc : HG_ERR_OOM;
+        HG_HIP(launch_fold_ln(b.w_qkv, b.ln1_w, b.ln1_b, b.b_qkv, b.wf_qkv, b.cs_qkv, b.bf_qkv, 3 * D, D, 0));
+        HG_HIP(launch_fold_ln(b.w_fc, b.ln2_w, b.ln2_b, b.b_fc, b.wf_fc, b.cs_fc, b.bf_fc, 4 * D, D, 0));
     }
     return HG_OK;
 }
@@ -347,7 +362,10 @@ int load_adapters(hg_ctx* c, const hg_adapter_weights* src, int layers) {
 inline size_t rup(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
 hipError_t gemm(hg_ctx* c, int epi, const GemmArgs& g, hipStream_t s) {
-    const bool prof = (c->prof_class == epi) && (2 * c->prof_n + 1 < c->prof_ev.size()) &&
+    // the LayerNorm-folding variants count as their base class (bench.py profiles the c_fc GEMM either way)
+    const int cls = epi == EPI_LN_BIAS_F16 ? EPI_BIAS_F16 : epi == EPI_LN_BIAS_QGELU_F16 ? EPI_BIAS_QGELU_F16
+                  : epi == EPI_RESID_LN_F32 ? EPI_BIAS_RESID_F32 : epi;
+    const bool prof = (c->prof_class == cls) && (2 * c->prof_n + 1 < c->prof_ev.size()) &&
                       (c->prof_M == 0 || (c->prof_M == g.M && c->prof_N == g.N && c->prof_K == g.K));
     if (prof) {
         hipError_t e = hipEventRecord(c->prof_ev[2 * c->prof_n], s);
@@ -372,35 +390,97 @@ struct AdapterCall {
 
 int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const AdapterCall& ac, hipStream_t s);
 
+// LayerNorm folded into the GEMMs: the residual GEMMs (out-proj, c_proj) also emit the fp16 copy of the updated
+// rows and per-row partial statistics; the consuming GEMMs (QKV, c_fc) read that copy and apply mean / rstd in
+// their epilogue.  Used when every GEMM of the block is eligible for the ring kernels and no adapter rewrites
+// the stream between the residual GEMM and its LayerNorm.  HG_LN_FUSE=0 selects the separate-LayerNorm path.
+bool ln_fuse_ok(hg_ctx* c, int M, int D) {
+    // Whenever the shapes are eligible (M >= 512): one arithmetic for every batch size keeps a row's result
+    // independent of the batch it is in.  HG_LN_FUSE=0 selects the separate-LayerNorm path.
+    const char* e = getenv("HG_LN_FUSE");
+    if (e && e[0] == '0') return false;
+    if (D % 256) return false;
+    GemmArgs g{};
+    float dummy = 0.f;
+    g.cs = &dummy; g.mr = &dummy; g.M = M; g.K = D; g.lda = D;
+    g.N = 3 * D; g.ldc = 3 * D;
+    if (!gemm_ln_ok(EPI_LN_BIAS_F16, g)) return false;
+    g.N = 4 * D; g.ldc = 4 * D;
+    if (!gemm_ln_ok(EPI_LN_BIAS_QGELU_F16, g)) return false;
+    GemmArgs r{};
+    r.out2 = (half_t*)&dummy; r.stats = &dummy; r.stats_ld = 4 * (D / 256); r.M = M; r.N = D; r.ldc = D;
+    r.K = D; r.lda = D;
+    if (!gemm_ln_ok(EPI_RESID_LN_F32, r)) return false;
+    r.K = 4 * D; r.lda = 4 * D;
+    return gemm_ln_ok(EPI_RESID_LN_F32, r);
+}
+
 int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, int D, int heads, bool causal,
-               hipStream_t s, float* trace, int trace_stride, const AdapterCall* ac) {
+               hipStream_t s, float* trace, int trace_stride, const AdapterCall* ac, bool ln_fold) {
     const int M = n_seq * L;
     float* x = (float*)c->x.p;
     half_t* h = (half_t*)c->h.p;
     half_t* qkv = (half_t*)c->qkv.p;
     half_t* att = (half_t*)c->att.p;
     half_t* fc = (half_t*)c->fc.p;
+    const bool adapters = ac && ac->enabled;
+    const bool fuse = ln_fold && !adapters && ln_fuse_ok(c, M, D);
+    const int sld = 4 * (D / 256);
+    float* mr = nullptr;
+    float* stats = nullptr;
+    if (fuse) {
+        int rc = ensure(c, c->mr, rup(M, 256) * 2 * 4);
+        if (!rc) rc = ensure(c, c->stats, rup(M, 256) * (size_t)sld * 2 * 4);
+        if (rc) return rc;
+        mr = (float*)c->mr.p;
+        stats = (float*)c->stats.p;
+        HG_HIP(launch_rowstats_cast(x, h, mr, M, D, s));
+    }
     for (size_t i = 0; i < blocks.size(); ++i) {
         const BlockW& b = blocks[i];
-        if (ac && ac->enabled && c->vit.adapters.size() > i && c->vit.adapters[i].present) {
+        if (adapters && c->vit.adapters.size() > i && c->vit.adapters[i].present) {
             int rc = run_adapter(c, c->vit.adapters[i], n_seq, L, D, *ac, s);
             if (rc) return rc;
         }
-        HG_HIP(launch_layernorm_f16(x, b.ln1_w, b.ln1_b, h, M, D, nullptr, 0, 1, s));
         GemmArgs g{};
-        g.A = h; g.lda = D; g.W = b.w_qkv; g.bias = b.b_qkv; g.out = qkv; g.ldc = 3 * D; g.M = M; g.N = 3 * D; g.K = D;
-        HG_HIP(gemm(c, EPI_BIAS_F16, g, s));
+        g.A = h; g.lda = D; g.out = qkv; g.ldc = 3 * D; g.M = M; g.N = 3 * D; g.K = D;
+        if (fuse) {
+            g.W = b.wf_qkv; g.bias = b.bf_qkv; g.cs = b.cs_qkv; g.mr = mr;
+            HG_HIP(gemm(c, EPI_LN_BIAS_F16, g, s));
+        } else {
+            HG_HIP(launch_layernorm_f16(x, b.ln1_w, b.ln1_b, h, M, D, nullptr, 0, 1, s));
+            g.W = b.w_qkv; g.bias = b.b_qkv;
+            HG_HIP(gemm(c, EPI_BIAS_F16, g, s));
+        }
         HG_HIP(launch_attention(qkv, att, n_seq, L, heads, causal, s));
         g = GemmArgs{};
         g.A = att; g.lda = D; g.W = b.w_out; g.bias = b.b_out; g.out = x; g.ldc = D; g.M = M; g.N = D; g.K = D;
-        HG_HIP(gemm(c, EPI_BIAS_RESID_F32, g, s));
-        HG_HIP(launch_layernorm_f16(x, b.ln2_w, b.ln2_b, h, M, D, nullptr, 0, 1, s));
+        if (fuse) {
+            g.out2 = h; g.stats = stats; g.stats_ld = sld;
+            HG_HIP(gemm(c, EPI_RESID_LN_F32, g, s));
+            HG_HIP(launch_finalize_stats(stats, mr, M, sld, 64, s));
+        } else {
+            HG_HIP(gemm(c, EPI_BIAS_RESID_F32, g, s));
+        }
         g = GemmArgs{};
-        g.A = h; g.lda = D; g.W = b.w_fc; g.bias = b.b_fc; g.out = fc; g.ldc = 4 * D; g.M = M; g.N = 4 * D; g.K = D;
-        HG_HIP(gemm(c, EPI_BIAS_QGELU_F16, g, s));
+        g.A = h; g.lda = D; g.out = fc; g.ldc = 4 * D; g.M = M; g.N = 4 * D; g.K = D;
+        if (fuse) {
+            g.W = b.wf_fc; g.bias = b.bf_fc; g.cs = b.cs_fc; g.mr = mr;
+            HG_HIP(gemm(c, EPI_LN_BIAS_QGELU_F16, g, s));
+        } else {
+            HG_HIP(launch_layernorm_f16(x, b.ln2_w, b.ln2_b, h, M, D, nullptr, 0, 1, s));
+            g.W = b.w_fc; g.bias = b.b_fc;
+            HG_HIP(gemm(c, EPI_BIAS_QGELU_F16, g, s));
+        }
         g = GemmArgs{};
         g.A = fc; g.lda = 4 * D; g.W = b.w_proj; g.bias = b.b_proj; g.out = x; g.ldc = D; g.M = M; g.N = D; g.K = 4 * D;
-        HG_HIP(gemm(c, EPI_BIAS_RESID_F32, g, s));
+        if (fuse && i + 1 < blocks.size()) {      // the last block is followed by ln_post / ln_final on selected rows
+            g.out2 = h; g.stats = stats; g.stats_ld = sld;
+            HG_HIP(gemm(c, EPI_RESID_LN_F32, g, s));
+            HG_HIP(launch_finalize_stats(stats, mr, M, sld, 64, s));
+        } else {
+            HG_HIP(gemm(c, EPI_BIAS_RESID_F32, g, s));
+        }
         if (trace) HG_HIP(launch_copy_rows(x, trace + (size_t)(i + 1) * trace_stride, n_seq, L, D, s));
     }
     return HG_OK;
@@ -581,7 +661,7 @@ int hg_load_vit(hg_ctx* c, const hg_vit_weights* w) {
     rc |= as_f32(c, v.owned, w->ln_post_bias, D, &v.lnpost_b, "visual.ln_post.bias");
     rc |= as_f16_T(c, v.owned, w->proj, D, v.E, &v.w_projT, "visual.proj");
     if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
-    rc = load_blocks(c, v.owned, w->blocks, v.layers, D, v.blocks);
+    rc = load_blocks(c, v.owned, w->blocks, v.layers, D, v.blocks, true);
     if (rc) return rc;
     rc = load_adapters(c, w->adapters, v.layers);
     if (rc) return rc;
@@ -619,7 +699,7 @@ int hg_load_text(hg_ctx* c, const hg_text_weights* w) {
     rc |= as_f32(c, t.owned, w->ln_final_bias, D, &t.lnf_b, "ln_final.bias");
     rc |= as_f16_T(c, t.owned, w->text_projection, D, t.E, &t.w_projT, "text_projection");
     if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
-    rc = load_blocks(c, t.owned, w->blocks, t.layers, D, t.blocks);
+    rc = load_blocks(c, t.owned, w->blocks, t.layers, D, t.blocks, false);
     if (rc) return rc;
     HG_HIP(hipDeviceSynchronize());
     t.loaded = true;
@@ -742,7 +822,7 @@ static int encode_image_impl(hg_ctx* c, const float* x_nchw, const float* priors
         ac.priors = priors ? priors + (size_t)b0 * N * 64 : nullptr;
         ac.mask = mask ? mask + (size_t)b0 * N : nullptr;
         ac.N = N;
-        rc = run_blocks(c, v.blocks, Bc, L, D, v.heads, false, s, tr, tstride, &ac);
+        rc = run_blocks(c, v.blocks, Bc, L, D, v.heads, false, s, tr, tstride, &ac, true);
         if (rc) return rc;
         half_t* h16 = (half_t*)c->head16.p;
         if (!variant_c) {
@@ -780,7 +860,9 @@ int hg_encode_image_prior(hg_ctx* c, const float* x_nchw, const float* priors, c
 static int text_tail(hg_ctx* c, int Tc, int Leff, const int32_t* eot, float* out, hipStream_t s) {
     Text& t = c->text;
     const int D = t.D, E = t.E;
-    int rc = run_blocks(c, t.blocks, Tc, Leff, D, t.heads, true, s, nullptr, 0, nullptr);
+    // the text tower keeps the separate LayerNorm: folding moved its parity error from 6.5e-4 to 7.4e-4 (worst
+    // prompt 9.0e-4) of the 1e-3 budget, for no measurable time gain at these sizes
+    int rc = run_blocks(c, t.blocks, Tc, Leff, D, t.heads, true, s, nullptr, 0, nullptr, false);
     if (rc) return rc;
     half_t* h16 = (half_t*)c->head16.p;
     // ln_final, select the EOT row, @ text_projection (clipnet/model.py:346-350); LN is row-wise so

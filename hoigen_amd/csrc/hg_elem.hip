@@ -426,4 +426,105 @@ hipError_t launch_copy_rows(const float* x, float* out, int B, int row_stride, i
     return hipGetLastError();
 }
 
+
+// ---- LayerNorm folding support ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fold_ln_kernel(const half_t* __restrict__ w16, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ bias,
+                                                      half_t* __restrict__ wf16, float* __restrict__ cs,
+                                                      float* __restrict__ bf, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float c = 0.f, b = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float w = (float)w16[(size_t)n * K + k];
+        const half_t wf = (half_t)(w * gamma[k]);
+        wf16[(size_t)n * K + k] = wf;
+        c += (float)wf;
+        b += w * beta[k];
+    }
+    c = wave_sum(c);
+    b = wave_sum(b);
+    if (lane == 0) {
+        cs[n] = c;
+        bf[n] = (bias ? bias[n] : 0.f) + b;
+    }
+}
+hipError_t launch_fold_ln(const half_t* w16, const float* gamma, const float* beta, const float* bias, half_t* wf16,
+                          float* cs, float* bf, int N, int K, hipStream_t s) {
+    hipLaunchKernelGGL(fold_ln_kernel, dim3((N + 3) / 4), dim3(256), 0, s, w16, gamma, beta, bias, wf16, cs, bf, N, K);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void rowstats_cast_kernel(const float* __restrict__ x, half_t* __restrict__ x16,
+                                                            float* __restrict__ mr, int M, int D) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    const f32x4* xp = reinterpret_cast<const f32x4*>(x + (size_t)r * D);
+    const int nc = D >> 2;
+    f32x4 v[LN_MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nc) {
+            v[i] = xp[c];
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            half4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = (half_t)v[i][e];
+            reinterpret_cast<half4*>(x16 + (size_t)r * D)[c] = h;
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nc) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
+    if (lane == 0) {
+        mr[2 * (size_t)r] = mean;
+        mr[2 * (size_t)r + 1] = rstd;
+    }
+}
+hipError_t launch_rowstats_cast(const float* x, half_t* x16, float* mr, int M, int D, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    if (D % 4 || D > 256 * LN_MAXC) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rowstats_cast_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, x16, mr, M, D);
+    return hipGetLastError();
+}
+
+// partial statistics of row m over nt column groups of `gw` columns each: (sum_k, M2_k = sum (x - mean_k)^2);
+// combined with Chan's parallel-variance formula (no E[x^2] - mean^2 cancellation)
+__global__ void finalize_stats_kernel(const float* __restrict__ stats, float* __restrict__ mr, int M, int nt, int gw) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float* sp = stats + (size_t)m * nt * 2;
+    float s1 = 0.f;
+    for (int t = 0; t < nt; ++t) s1 += sp[2 * t];
+    const float D = (float)(nt * gw);
+    const float mean = s1 / D;
+    float m2 = 0.f;
+    for (int t = 0; t < nt; ++t) {
+        const float d = sp[2 * t] / (float)gw - mean;
+        m2 += sp[2 * t + 1] + (float)gw * d * d;
+    }
+    mr[2 * (size_t)m] = mean;
+    mr[2 * (size_t)m + 1] = 1.0f / sqrtf(m2 / D + 1e-5f);
+}
+hipError_t launch_finalize_stats(const float* stats, float* mr, int M, int nt, int gw, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    hipLaunchKernelGGL(finalize_stats_kernel, dim3((M + 255) / 256), dim3(256), 0, s, stats, mr, M, nt, gw);
+    return hipGetLastError();
+}
+
 }  // namespace hg

@@ -178,6 +178,8 @@ hipError_t launch_gemm(int epi, const GemmArgs& a, hipStream_t s) {
         return (e && e[0] == 's') ? 1 : 0;      // HG_GEMM=simple: A/B against the 128x128 kernel
     }();
     if (a.M <= 0) return hipSuccess;
+    const bool ln = (epi == EPI_LN_BIAS_F16 || epi == EPI_LN_BIAS_QGELU_F16 || epi == EPI_RESID_LN_F32);
+    if (ln) return gemm_ln_ok(epi, a) ? launch_gemm_ring(epi, a, s) : hipErrorInvalidValue;   // ring kernels only
     if (!force_simple && gemm_ring_ok(a)) return launch_gemm_ring(epi, a, s);
     return launch_gemm_simple(epi, a, s);
 }

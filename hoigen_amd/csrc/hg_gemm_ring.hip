@@ -65,8 +65,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     constexpr bool RESID = (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_SCALE_RESID_F32);
     // RESID at MF = 2: the residual rows are fetched one K-tile before the epilogue (64 spare VGPRs)
     constexpr bool XPRE = RESID && MF == 2;
-    constexpr int R = XPRE ? E : 0;                    // x prefetch loads per wave
-    constexpr int BIAS_OFF = 2 * STAGE;                // bias[N] staged in LDS behind the ring
+    // folded LayerNorm (EPI_LN_*): (mean, rstd) of this lane's 2*MF rows are fetched one K-tile ahead as well
+    constexpr bool LNC = (EPI == EPI_LN_BIAS_F16 || EPI == EPI_LN_BIAS_QGELU_F16);
+    constexpr int R = XPRE ? E : 0;                    // residual prefetch loads per wave in the last K-tile
+    constexpr int BIAS_OFF = 2 * STAGE;                // bias[N] (and cs[N] for EPI_LN_*) staged in LDS behind the ring
+    const int MR_OFF = BIAS_OFF + 2 * p.N * 4;         // EPI_LN_*: (mean, rstd) of the tile's BM rows, 8 B each
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef HG_STAMPS
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_beg = 0, t_all = 0;
@@ -124,6 +127,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     const __amdgpu_buffer_rsrc_t rsW =
         __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (unsigned)((size_t)p.N * p.K * 2), 0x00020000);
 
+    const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.mr, 0, LNC ? (unsigned)((size_t)tiles_m_all * BM * 8) : 0u, 0x00020000);
     // ---- DMA source offsets (bytes, per lane; identical for every tile and K-step)
     int voffA[2][GA], voffW[2][GB];
 #pragma unroll
@@ -270,8 +275,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     // global load would wait for every older DMA of the ring)
     {
         const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int i = tid; i < p.N / 4; i += 512)
+        for (int i = tid; i < p.N / 4; i += 512) {
             *reinterpret_cast<f32x4*>(smem + BIAS_OFF + i * 16) = p.bias ? reinterpret_cast<const f32x4*>(p.bias)[i] : z;
+            if constexpr (LNC)
+                *reinterpret_cast<f32x4*>(smem + BIAS_OFF + p.N * 4 + i * 16) = reinterpret_cast<const f32x4*>(p.cs)[i];
+        }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
     // ---- prologue: stream positions 0 and 1 (A1 of position 1 is issued in the first P1)
@@ -300,6 +308,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
         const int m0 = tm * BM, n0 = tn * 256;
         zero_acc();
         f32x4 xres[XPRE ? 2 : 1][XPRE ? 2 : 1][XPRE ? MF : 1][XPRE ? 2 : 1];
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
         for (int kt = 0; kt < nk; ++kt, ++g) {
             const int buf = (g & 1) * STAGE;
             const bool more = g + 2 < S;          // a K-tile two positions ahead exists
@@ -308,6 +317,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             // ---------------- P1: fetch A0(t), W0(t); refill A1(t+1); then quadrant (0,0)
             read_A(0, buf);
             read_W(I0{}, buf);
+            if constexpr (LNC) {
+                // (mean, rstd) of this tile's rows -> LDS, one small DMA per wave (BM/8 rows x 8 B), a K-tile
+                // ahead of the last one: by the last P4's counted wait it is more than N1 operations old, and that
+                // phase's barriers publish it to every wave before the epilogue (the waits run one operation
+                // stricter until it has retired)
+                if (kt == nk - 2 && lane < BM / 16)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsM, (HG_LDS void*)(smem + MR_OFF + wave * BM), 16, lane * 16,
+                                                             (m0 + wave * (BM / 8)) * 8, 0, 0);
+            }
             if (g + 1 < S) issue_A(1, 0, GA);     // A1 of position g+1 (ld state already at g+1)
             if constexpr (XPRE) {
                 if (xl) {
@@ -380,7 +398,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                         for (int g2 = 0; g2 < 2; ++g2) asm volatile("" ::"v"(acc[a][b][f][g2]));
             continue;
         }
-        constexpr bool F16OUT = (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_BIAS_RELU_F16);
+        constexpr bool F16OUT = (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_BIAS_RELU_F16 || LNC);
         if constexpr (F16OUT) {
             // fp16 outputs: a lane holds 4 consecutive columns (8 B) of one row.  v_permlane16_swap pairs the
             // accumulator tiles f, f+1 (same columns, rows 16 apart) so that even 16-lane groups end up with 8
@@ -394,14 +412,28 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                 for (int f = 0; f < MF; f += 2) {
                     const int mX = m0 + ha * (BM / 2) + wm * MF * 16 + f * 16 + (lane & 15);
                     const int m = mX + ((q & 1) ? 16 : 0);
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    f32x2 mrx = {0.f, 1.f}, mry = {0.f, 1.f};       // (mean, rstd) of rows mX and mX + 16
+                    if constexpr (LNC) {
+                        mrx = *reinterpret_cast<const f32x2*>(smem + MR_OFF + (mX - m0) * 8);
+                        mry = *reinterpret_cast<const f32x2*>(smem + MR_OFF + (mX - m0 + 16) * 8);
+                    }
 #pragma unroll
                     for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
                         for (int g2 = 0; g2 < 2; ++g2) {
                             const int nb = n0 + hb * 128 + wn * 32 + g2 * 16;
                             const f32x4 bv = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (nb + 4 * q) * 4);
-                            f32x4 vx = acc[ha][hb][f][g2] + bv, vy = acc[ha][hb][f + 1][g2] + bv;
-                            if constexpr (EPI == EPI_BIAS_QGELU_F16) {
+                            f32x4 vx, vy;
+                            if constexpr (LNC) {   // rstd * (acc - mean * cs) + bias'
+                                const f32x4 cv = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + p.N * 4 + (nb + 4 * q) * 4);
+                                vx = (acc[ha][hb][f][g2] - cv * mrx[0]) * mrx[1] + bv;
+                                vy = (acc[ha][hb][f + 1][g2] - cv * mry[0]) * mry[1] + bv;
+                            } else {
+                                vx = acc[ha][hb][f][g2] + bv;
+                                vy = acc[ha][hb][f + 1][g2] + bv;
+                            }
+                            if constexpr (EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_LN_BIAS_QGELU_F16) {
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) { vx[r] = quick_gelu_r(vx[r]); vy[r] = quick_gelu_r(vy[r]); }
                             }
@@ -471,7 +503,8 @@ template <int MF, int EPI>
 static hipError_t launch_ring_t(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = 64 * MF;
     constexpr int RING = 2 * (2 * MF * 4096 + 2 * 16384);
-    const int LDS = RING + a.N * 4;                               // ring + bias[N]
+    constexpr bool LNC = (EPI == EPI_LN_BIAS_F16 || EPI == EPI_LN_BIAS_QGELU_F16);
+    const int LDS = RING + a.N * 4 * (LNC ? 2 : 1) + (LNC ? BM * 8 : 0);   // ring + bias[N] (+ cs[N] + (mean, rstd)[BM])
     if (LDS > 160 * 1024) return hipErrorInvalidValue;
     static bool attr_set = false;
     static int n_cu = 256;
@@ -543,13 +576,21 @@ bool gemm_ring_ok(const GemmArgs& a) {
     return true;
 }
 
+bool gemm_ln_ok(int epi, const GemmArgs& a) {
+    if (!gemm_ring_ok(a)) return false;
+    if (epi == EPI_RESID_LN_F32) return gemm_ring2_ok(a) && a.out2 && a.stats && a.stats_ld == 4 * (a.N / 256);
+    return a.cs && a.mr && a.N <= 3584;      // 128 KiB ring + 2 * N * 4 + 2 KiB of LDS; mr readable for padded rows
+}
+
 hipError_t launch_gemm_ring(int epi, const GemmArgs& a, hipStream_t s) {
+    if (epi == EPI_RESID_LN_F32) return launch_gemm_ring2(epi, a, s);
+    const bool lnc = (epi == EPI_LN_BIAS_F16 || epi == EPI_LN_BIAS_QGELU_F16);
     // 256x256 tiles when they fill the chip evenly enough, else 128x256 (N = 768 GEMMs: 591 vs 1182 tiles)
     const int t256 = ((a.M + 255) / 256) * (a.N / 256);
     const int rounds = (t256 + 255) / 256;
     static const int force_big = []() { const char* e = getenv("HG_RING_BIG"); return e ? atoi(e) : 0; }();
     const bool big = force_big == 1 ? true : (force_big == 2 || force_big == 3) ? false : (t256 >= 256 && (double)t256 / (rounds * 256.0) >= 0.9);
-    if (!big && force_big != 3 && gemm_ring2_ok(a)) return launch_gemm_ring2(epi, a, s);   // 128x256, two-phase
+    if (!big && force_big != 3 && !lnc && gemm_ring2_ok(a)) return launch_gemm_ring2(epi, a, s);   // 128x256, two-phase
 #define HG_RING(E)                                                         \
     case E:                                                                \
         return big ? launch_ring_t<4, E>(a, s) : launch_ring_t<2, E>(a, s)
@@ -562,6 +603,8 @@ hipError_t launch_gemm_ring(int epi, const GemmArgs& a, hipStream_t s) {
         HG_RING(EPI_PATCH_F32);
         HG_RING(EPI_BIAS_RELU_F32);
         HG_RING(EPI_SCALE_RESID_F32);
+        HG_RING(EPI_LN_BIAS_F16);
+        HG_RING(EPI_LN_BIAS_QGELU_F16);
         default: return hipErrorInvalidValue;
     }
 #undef HG_RING

@@ -35,9 +35,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
     constexpr int NST = 3;
     constexpr int GA = 2, GW = 4;                      // DMA instructions per wave: A tile, both W halves
     constexpr int NWT = GW + GA + GW;                  // younger DMAs when A,W(t+1) must have landed
-    constexpr bool RESID = (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_SCALE_RESID_F32);
+    constexpr bool RLN = (EPI == EPI_RESID_LN_F32);    // residual + fp16 copy + LayerNorm statistics for the next GEMM
+    constexpr bool RESID = (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_SCALE_RESID_F32 || RLN);
     constexpr bool F16OUT = (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_BIAS_RELU_F16);
-    constexpr int E = F16OUT ? 8 : 16;                 // epilogue store instructions per wave
+    constexpr int E = F16OUT ? 8 : (RLN ? 28 : 16);    // epilogue store instructions per wave
     constexpr int R = RESID ? 16 : 0;                  // residual-row prefetch loads per wave
     constexpr int BIAS_OFF = NST * STAGE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -317,6 +318,69 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                         if (m < p.M) *reinterpret_cast<u32x4*>(outp + (size_t)m * p.ldc + nb + 4 * (q & ~1)) = o;
                     }
             }
+        } else if constexpr (RLN) {
+            // x' = x + acc + bias (fp32, in place) ; x16 = fp16(x') ; per row and per wave column group (64
+            // columns) the pair (sum, sum of squared deviations from the group mean) for the next LayerNorm
+            half_t* out2 = p.out2;
+            const int sg = tn * 4 + wn;                     // column group of this wave
+#pragma unroll
+            for (int ha = 0; ha < 2; ++ha) {
+                half4 h16[2][2][2];                         // [f][hb][g2]
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const int m = m0 + ha * 64 + wm * 32 + f * 16 + (lane & 15);
+                    f32x4 v[2][2];
+                    float sum = 0.f;
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                        for (int g2 = 0; g2 < 2; ++g2) {
+                            const int n = n0 + hb * 128 + wn * 32 + g2 * 16 + 4 * q;
+                            v[hb][g2] = xres[ha][hb][f][g2] +
+                                        (acc[ha][hb][f][g2] + *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + n * 4));
+                            sum += (v[hb][g2][0] + v[hb][g2][1]) + (v[hb][g2][2] + v[hb][g2][3]);
+                            if (m < p.M)
+                                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v[hb][g2];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) h16[f][hb][g2][e] = (half_t)v[hb][g2][e];
+                        }
+                    sum += __shfl_xor(sum, 16, 64);
+                    sum += __shfl_xor(sum, 32, 64);
+                    const float gm = sum * (1.0f / 64.0f);
+                    float m2 = 0.f;
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                        for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float d = v[hb][g2][e] - gm;
+                                m2 = fmaf(d, d, m2);
+                            }
+                    m2 += __shfl_xor(m2, 16, 64);
+                    m2 += __shfl_xor(m2, 32, 64);
+                    if (q == 0 && m < p.M) {
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        *reinterpret_cast<f32x2*>(p.stats + ((size_t)m * p.stats_ld + sg) * 2) = f32x2{sum, m2};
+                    }
+                }
+                // fp16 copy: pair the row tiles f = 0, 1 through v_permlane16_swap -> 16-byte stores
+                const int mX = m0 + ha * 64 + wm * 32 + (lane & 15);
+                const int m = mX + ((q & 1) ? 16 : 0);
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                    for (int g2 = 0; g2 < 2; ++g2) {
+                        const int nb = n0 + hb * 128 + wn * 32 + g2 * 16;
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                        const u32x2 ux = __builtin_bit_cast(u32x2, h16[0][hb][g2]), uy = __builtin_bit_cast(u32x2, h16[1][hb][g2]);
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(ux[0], uy[0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(ux[1], uy[1], false, false);
+                        const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                        if (m < p.M) *reinterpret_cast<u32x4*>(out2 + (size_t)m * p.ldc + nb + 4 * (q & ~1)) = o;
+                    }
+            }
         } else {
 #pragma unroll
             for (int ha = 0; ha < 2; ++ha)
@@ -404,6 +468,7 @@ hipError_t launch_gemm_ring2(int epi, const GemmArgs& a, hipStream_t s) {
         case EPI_PATCH_F32: return launch_ring2_t<EPI_PATCH_F32>(a, s);
         case EPI_BIAS_RELU_F32: return launch_ring2_t<EPI_BIAS_RELU_F32>(a, s);
         case EPI_SCALE_RESID_F32: return launch_ring2_t<EPI_SCALE_RESID_F32>(a, s);
+        case EPI_RESID_LN_F32: return launch_ring2_t<EPI_RESID_LN_F32>(a, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -16,7 +16,15 @@ enum Epilogue : int {
     EPI_BIAS_F32 = 4,        // out fp32 = acc + bias (bias may be null)
     EPI_PATCH_F32 = 5,       // patch embedding: row m=(b,t) -> out row b*L+1+t, + pos[1+t]
     EPI_BIAS_RELU_F32 = 6,   // out fp32 = relu(acc + bias)
-    EPI_SCALE_RESID_F32 = 7  // out fp32 += (acc + bias) * pos[n]   (adapter up_proj * scale, residual)
+    EPI_SCALE_RESID_F32 = 7, // out fp32 += (acc + bias) * pos[n]   (adapter up_proj * scale, residual)
+    // LayerNorm folded into the GEMM (ring kernels only): A = raw fp16 copy of the residual rows, W = gamma-folded
+    // weight, cs[n] = sum_k W'[n][k], bias' = bias + W beta, mr[m] = (mean, rstd) of row m:
+    //     out = rstd[m] * (acc - mean[m] * cs[n]) + bias'[n]
+    EPI_LN_BIAS_F16 = 8,
+    EPI_LN_BIAS_QGELU_F16 = 9,
+    // residual update that also emits what the next folded-LN GEMM needs (ring2 kernel only):
+    //     out fp32 += acc + bias;  out2 fp16 = the updated rows;  stats[m][tile_n] = (sum, sum of squares) over the tile's columns
+    EPI_RESID_LN_F32 = 10
 };
 
 struct GemmArgs {
@@ -28,7 +36,12 @@ struct GemmArgs {
     int lda, ldc;
     int M, N, K;
     int G, L;          // EPI_PATCH: patches per image, tokens per image
-    unsigned long long* dbg = nullptr;   // diagnostics: s_memtime stamps (HG_STAMPS=1), normally null
+    const float* cs = nullptr;   // EPI_LN_*: [N] column sums of the folded weight
+    const float* mr = nullptr;   // EPI_LN_*: [M][2] (mean, rstd) per row
+    half_t* out2 = nullptr;      // EPI_RESID_LN: fp16 copy of the updated rows, leading dimension ldc
+    float* stats = nullptr;      // EPI_RESID_LN: [M][stats_ld][2] partial (sum, sumsq) per row and wave column group
+    int stats_ld = 0;            //   = 4 * N / 256
+    unsigned long long* dbg = nullptr;   // diagnostics: s_memtime totals (HG_STAMPS build), normally null
 };
 
 // Requirements: N % 128 == 0, K % 64 == 0, A readable for rows < M, 16-byte aligned rows.
@@ -40,6 +53,9 @@ double gemm_flops(const GemmArgs& a);
 bool gemm_ring_ok(const GemmArgs& a);
 hipError_t launch_gemm_ring(int epi, const GemmArgs& a, hipStream_t s);
 bool gemm_ring2_ok(const GemmArgs& a);
+// LayerNorm-folding epilogues exist only in the ring kernels: EPI_LN_* in gemm_ring (bias + column sums must fit
+// behind the ring), EPI_RESID_LN_F32 in gemm_ring2
+bool gemm_ln_ok(int epi, const GemmArgs& a);
 hipError_t launch_gemm_ring2(int epi, const GemmArgs& a, hipStream_t s);
 hipError_t launch_gemm_simple(int epi, const GemmArgs& a, hipStream_t s);
 
@@ -86,6 +102,15 @@ hipError_t launch_vae_loss(const float* recon, const float* x, const float* mean
 hipError_t launch_split_global_local(const float* tok, float* glob, float* local, int B, int L, int E,
                                      hipStream_t s);
 hipError_t launch_copy_rows(const float* x, float* out, int B, int row_stride, int D, hipStream_t s);
+// ---- LayerNorm folding support (DESIGN.md §4 "LayerNorm folded into the GEMMs")
+// W16 [N,K], gamma/beta [K], bias [N]  ->  Wf16 = fp16(W * gamma), cs[n] = sum_k float(Wf16[n][k]), bf[n] = bias[n] + sum_k W[n][k] * beta[k]
+hipError_t launch_fold_ln(const half_t* w16, const float* gamma, const float* beta, const float* bias, half_t* wf16,
+                          float* cs, float* bf, int N, int K, hipStream_t s);
+// x fp32 [M,D] -> x16 fp16 copy and mr[m] = (mean, rstd) of row m (eps 1e-5, biased variance)
+hipError_t launch_rowstats_cast(const float* x, half_t* x16, float* mr, int M, int D, hipStream_t s);
+// stats [M][nt][2]: per column group of gw columns (sum, sum of squared deviations from the group mean)
+// -> mr [M][2] (mean, rstd) over the nt * gw columns, eps 1e-5
+hipError_t launch_finalize_stats(const float* stats, float* mr, int M, int nt, int gw, hipStream_t s);
 
 // ---- adapter (variant C) --------------------------------------------------------------------
 struct AdapterDev {      // device pointers, all fp32 except the two MFMA operands

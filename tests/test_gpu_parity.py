@@ -307,6 +307,25 @@ def test_batch256_invariance_and_determinism(fullA):
     assert torch.equal(out300[:256], out) and torch.equal(out300[256:], out[:44])
 
 
+def test_layernorm_folding_matches_separate_layernorm(fullA, g0, monkeypatch):
+    """The vision tower folds LayerNorm into its GEMMs for M >= 512; HG_LN_FUSE=0 selects the separate-LayerNorm
+    path.  Both must sit within the parity tolerance of the reference and of each other; the text tower always
+    uses the separate LayerNorm (its error budget is tighter)."""
+    g = dict(np.load(f"{G}/g2_vitb16_image.npz"))
+    img = torch.from_numpy(synth.crops(4, 224, seed=1234)).to(dev())
+    ids = clip.tokenize(g0["obj81"]["text"]).to(dev())
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HG_LN_FUSE", mode)
+        outs[mode] = (fullA.visual.forward_trace(img)[0], fullA.encode_text(ids).float())
+        e = check(outs[mode][0], g["encode_image"], what=f"encode_image HG_LN_FUSE={mode}")
+        print(f"\nencode_image rel-L2 vs reference, HG_LN_FUSE={mode}: {e:.3e}")
+    monkeypatch.delenv("HG_LN_FUSE")
+    assert not torch.equal(outs["1"][0], outs["0"][0]), "the switch did not change the executed path"
+    check(outs["1"][0], outs["0"][0].cpu().numpy(), what="folded vs separate LayerNorm (image)")
+    assert torch.equal(outs["1"][1], outs["0"][1]), "the text tower does not fold LayerNorm"
+
+
 def test_text_truncation_is_exact_selection(fullA, g0):
     ids = ids_from_g0(g0, "coop_hoi600", 64).to(dev())
     fullA.truncate_text = True
