@@ -159,7 +159,7 @@ def main():
                                    "(BASELINE.json configs[1])",
                        "batch_per_gpu": args.batch, "global_batch": world * args.batch,
                        "parallelism": f"dp{world}" + (" + all_gather[256x512 f32]/step" if world > 1 else "")},
-            "roofline": {"bound": "mfma", "kernel": f"gemm_nt (c_fc: M={mnk[0]} N={mnk[1]} K={mnk[2]}, bias+QuickGELU->f16)",
+            "roofline": {"bound": "mfma", "kernel": f"gemm_ring (c_fc: M={mnk[0]} N={mnk[1]} K={mnk[2]}, LayerNorm-folded bias+QuickGELU->f16)",
                          "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "avg_kernel_ms": round(avg_ms.value, 4), "launches_timed": launches.value,
