@@ -103,6 +103,7 @@ SIGNATURES = {
     "hg_assemble_prompts": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "hg_l2_normalize": (_I, [_P, _P, _I, _I, _P, _P]),
     "hg_vae_loss": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
+    "hg_preprocess_crops": (_I, [_P, _P, _I, _I, _P, _I, _I, _I, C.c_uint32, _P, _P, _P]),
     "hg_workspace_bytes": (_I, [_P, C.POINTER(C.c_uint64)]),
     "hg_test_gemm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "hg_profile_begin": (_I, [_P, _I, _I]),

@@ -9,6 +9,7 @@
 //   linear weights      fp16 [N, K]      exactly nn.Linear's [out, in] -> both GEMM operands K-contiguous
 //   proj/text_projection fp16 [E, D]     transposed once at load ([D,E] in the state dict)
 //   biases, LN affine, embeddings, positional: fp32
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -96,7 +97,7 @@ struct hg_ctx {
     Vae vae[HG_MAX_SLOTS];
     Mlp mlp[HG_MAX_SLOTS];
     // workspace (grow-only)
-    Buf x, h, qkv, att, fc, head16, tok32, small, i32, ad32, ad16, adkv, mr, stats;
+    Buf x, h, qkv, att, fc, head16, tok32, small, i32, ad32, ad16, adkv, mr, stats, pre, pretab;
     int max_chunk_img = 256;
     int max_chunk_txt = 640;
     int max_chunk_rows = 32768;
@@ -553,7 +554,7 @@ void hg_destroy(hg_ctx* c) {
     for (auto& v : c->vae) free_all(v.owned);
     for (auto& m : c->mlp) free_all(m.owned);
     Buf* bufs[] = {&c->x, &c->h, &c->qkv, &c->att, &c->fc, &c->head16, &c->tok32, &c->small, &c->i32,
-                   &c->ad32, &c->ad16, &c->adkv};
+                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->stats, &c->pre, &c->pretab};
     for (Buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
@@ -564,6 +565,75 @@ const char* hg_last_error(hg_ctx* c) { return c ? c->err.c_str() : "null context
 
 // Test hook: out[M,N] (fp32) (+)= epilogue(A[M,K] x W[N,K]^T) with the operands rounded to fp16 on the device.
 // kernel: 0 = dispatcher's choice, 1 = simple 128x128 kernel, 2 = persistent ring kernel.
+int hg_preprocess_crops(hg_ctx* c, const uint8_t* img, int H, int W, const int32_t* boxes_host, int n, int n_px,
+                        int pad_square, uint32_t background, float* out, uint8_t* out_u8, void* stream) {
+    if (!c) return HG_ERR_INVALID;
+    if (n == 0) return HG_OK;
+    if (!img || !boxes_host || !out || n < 0 || H <= 0 || W <= 0 || n_px <= 0 || n_px > 4096)
+        return fail(c, HG_ERR_INVALID, "hg_preprocess_crops: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    HG_HIP(hipSetDevice(c->device));
+    // host part: geometry of every crop (sizes, padding, resize target, centre-crop offsets, tap counts, the
+    // source rows the vertical pass needs); the weight tables themselves are filled on the device
+    std::vector<int32_t> head((size_t)n * (HG_PRE_HDR + 1), 0);      // headers, then the n table offsets
+    int32_t* off = head.data() + (size_t)n * HG_PRE_HDR;
+    size_t words = 0, tmp = 0;
+    int max_rows = 0;
+    for (int b = 0; b < n; ++b) {
+        const int32_t* bx = boxes_host + 4 * (size_t)b;
+        const int cw = bx[2] - bx[0], ch = bx[3] - bx[1];
+        if (cw <= 0 || ch <= 0) return fail(c, HG_ERR_INVALID, "hg_preprocess_crops: empty box %d", b);
+        int sw = cw, sh = ch, px = 0, py = 0;
+        if (pad_square && cw != ch) {                       // expand2square: centred, floor((side - short) / 2)
+            if (cw > ch) py = (cw - ch) / 2; else px = (ch - cw) / 2;
+            sw = sh = cw > ch ? cw : ch;
+        }
+        // torchvision Resize: short side -> n_px, long side -> int(n_px * long / short); CenterCrop offsets
+        // int(round(d / 2.0)) with Python's round-half-to-even
+        int nw, nh;
+        if (sw <= sh) { nw = n_px; nh = (int)((double)((long long)n_px * sh) / (double)sw); }
+        else { nw = (int)((double)((long long)n_px * sw) / (double)sh); nh = n_px; }
+        const int left = (int)nearbyint((double)(nw - n_px) / 2.0), top = (int)nearbyint((double)(nh - n_px) / 2.0);
+        auto taps = [](int in, int outn) {
+            const double sc = (double)in / (double)outn, fs = sc < 1.0 ? 1.0 : sc;
+            return (int)ceil(2.0 * fs) * 2 + 1;
+        };
+        auto first_tap = [](int in, int outn, int idx) {
+            const double sc = (double)in / (double)outn, fs = sc < 1.0 ? 1.0 : sc;
+            const int v = (int)(((double)idx + 0.5) * sc - 2.0 * fs + 0.5);
+            return v < 0 ? 0 : v;
+        };
+        auto end_tap = [](int in, int outn, int idx) {
+            const double sc = (double)in / (double)outn, fs = sc < 1.0 ? 1.0 : sc;
+            const int v = (int)(((double)idx + 0.5) * sc + 2.0 * fs + 0.5);
+            return v > in ? in : v;
+        };
+        const int ks_h = taps(sw, nw), ks_v = taps(sh, nh);
+        const int row_lo = first_tap(sh, nh, top), n_rows = end_tap(sh, nh, top + n_px - 1) - row_lo;
+        if (tmp + (size_t)n_rows * n_px * 3 >= ((size_t)1 << 31))
+            return fail(c, HG_ERR_INVALID, "hg_preprocess_crops: scratch of one call >= 2 GiB; split the boxes");
+        int32_t* h = head.data() + (size_t)b * HG_PRE_HDR;
+        h[0] = bx[0]; h[1] = bx[1]; h[2] = cw; h[3] = ch; h[4] = px; h[5] = py; h[6] = sw; h[7] = sh;
+        h[8] = ks_h; h[9] = ks_v; h[10] = row_lo; h[11] = n_rows; h[12] = (int32_t)tmp; h[13] = (int32_t)background;
+        h[14] = nw; h[15] = nh; h[16] = left; h[17] = top;
+        off[b] = (int32_t)words;
+        words += (size_t)n_px * (4 + ks_h + ks_v);
+        tmp += ((size_t)n_rows * n_px * 3 + 15) / 16 * 16;
+        if (n_rows > max_rows) max_rows = n_rows;
+        if (words >= ((size_t)1 << 30)) return fail(c, HG_ERR_INVALID, "hg_preprocess_crops: too many boxes in one call");
+    }
+    int rc = ensure(c, c->pre, tmp ? tmp : 16);
+    if (!rc) rc = ensure(c, c->pretab, (head.size() + words) * 4);
+    if (rc) return rc;
+    int32_t* head_d = (int32_t*)c->pretab.p;                          // [n][HG_PRE_HDR] | off[n] | tables
+    int32_t* tab_off = head_d + (size_t)n * HG_PRE_HDR;
+    int32_t* tab = tab_off + n;
+    HG_HIP(hipMemcpyAsync(head_d, head.data(), head.size() * 4, hipMemcpyHostToDevice, s));
+    HG_HIP(hipStreamSynchronize(s));      // `head` is a stack-lifetime host buffer
+    HG_HIP(launch_preprocess(img, H, W, head_d, tab, tab_off, n, n_px, max_rows, (uint8_t*)c->pre.p, out, out_u8, s));
+    return HG_OK;
+}
+
 int hg_test_gemm(hg_ctx* c, const float* a, const float* w, const float* bias, float* out, int M, int N, int K,
                  int epi, int kernel, void* stream) {
     if (!c || !a || !w || !out || M <= 0) return HG_ERR_INVALID;
@@ -625,7 +695,7 @@ int hg_profile_end(hg_ctx* c, double* avg_ms, int32_t* launches, double* flops_p
 int hg_workspace_bytes(hg_ctx* c, uint64_t* bytes) {
     if (!c || !bytes) return HG_ERR_INVALID;
     Buf* bufs[] = {&c->x, &c->h, &c->qkv, &c->att, &c->fc, &c->head16, &c->tok32, &c->small, &c->i32,
-                   &c->ad32, &c->ad16, &c->adkv};
+                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->stats, &c->pre, &c->pretab};
     uint64_t t = 0;
     for (Buf* b : bufs) t += b->bytes;
     *bytes = t;

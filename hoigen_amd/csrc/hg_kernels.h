@@ -112,6 +112,14 @@ hipError_t launch_rowstats_cast(const float* x, half_t* x16, float* mr, int M, i
 // -> mr [M][2] (mean, rstd) over the nt * gw columns, eps 1e-5
 hipError_t launch_finalize_stats(const float* stats, float* mr, int M, int nt, int gw, hipStream_t s);
 
+#define HG_PRE_HDR 24   // header words per box in the pre-processing table (layout: hg_preproc.hip)
+// ---- crop pre-processing (hg_preproc.hip): head = per-box headers written by the host, tab receives the weight
+// tables at word offsets tab_off[box]; tmp = uint8 scratch for the horizontal pass; out fp32 [n,3,n_px,n_px]; out_u8 (nullable) uint8
+// [n,n_px,n_px,3] before normalisation
+hipError_t launch_preprocess(const uint8_t* img, int H, int W, const int32_t* head, int32_t* tab,
+                             const int32_t* tab_off, int n, int n_px, int max_rows, uint8_t* tmp, float* out,
+                             uint8_t* out_u8, hipStream_t s);
+
 // ---- adapter (variant C) --------------------------------------------------------------------
 struct AdapterDev {      // device pointers, all fp32 except the two MFMA operands
     const half_t* down_w;   // [d, D] fp16

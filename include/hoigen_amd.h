@@ -183,6 +183,16 @@ int hg_assemble_prompts(hg_ctx*, const float* prefix, const float* suffix, const
                         int D, float* prompts, void* stream);
 /* x / x.norm(dim=-1, keepdim=True) (main_coop_vae.py:438,466); in == out allowed. */
 int hg_l2_normalize(hg_ctx*, const float* x, int R, int D, float* out, void* stream);
+/* Crop pre-processing in front of encode_image: for every box of one image
+ *   image.crop(box)                       pre_images/crop_images.py:204-219 (PIL: zeros outside the image)
+ *   [expand2square(crop, background)]     utils_tip_cache_and_union_finetune.py:201-212  (pad_square != 0)
+ *   Resize(n_px, BICUBIC), CenterCrop(n_px), ToTensor, Normalize      clipnet/clip.py:75-82
+ * with Pillow's 8-bit resampling arithmetic (bit-exact uint8).  img: uint8 [H,W,3] RGB on the device;
+ * boxes_host: int32 [n][4] = (x0, y0, x1, y1) in HOST memory (PIL convention, may leave the image);
+ * background: 0x00BBGGRR; out: fp32 [n,3,n_px,n_px] (device); out_u8: optional uint8 [n,n_px,n_px,3] (device),
+ * the resized crops before normalisation. */
+int hg_preprocess_crops(hg_ctx*, const uint8_t* img, int H, int W, const int32_t* boxes_host, int n, int n_px,
+                        int pad_square, uint32_t background, float* out, uint8_t* out_u8, void* stream);
 /* vae_loss forward value (main_coop_vae.py:300-303) -> loss[1] fp32. */
 int hg_vae_loss(hg_ctx*, const float* recon, const float* x, const float* mean, const float* logvar,
                 int R, int D, float* loss, void* stream);
