@@ -78,6 +78,11 @@ class hg_mlp_weights(C.Structure):
                 ("w4", hg_tensor), ("b4", hg_tensor)]
 
 
+class hg_cache_weights(C.Structure):
+    _fields_ = [("weight", hg_tensor), ("bias", hg_tensor), ("labels", hg_tensor), ("sample_lens", hg_tensor),
+                ("S", C.c_int32), ("K", C.c_int32), ("C", C.c_int32), ("post_div", C.c_float)]
+
+
 _P = C.c_void_p
 _I = C.c_int
 # name -> (restype, argtypes); must list every symbol of include/hoigen_amd.h (tests check this)
@@ -103,6 +108,8 @@ SIGNATURES = {
     "hg_assemble_prompts": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "hg_l2_normalize": (_I, [_P, _P, _I, _I, _P, _P]),
     "hg_vae_loss": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
+    "hg_load_cache": (_I, [_P, _I, _P]),
+    "hg_cache_logits": (_I, [_P, _I, _P, _I, _P, _P]),
     "hg_preprocess_crops": (_I, [_P, _P, _I, _I, _P, _I, _I, _I, C.c_uint32, _P, _P, _P]),
     "hg_workspace_bytes": (_I, [_P, C.POINTER(C.c_uint64)]),
     "hg_test_gemm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -1,0 +1,70 @@
+"""Cache-model (Tip-adapter) logits on the embeddings produced by the hot path.
+
+Counterpart of the expressions in upt_tip_cache_model_free_finetune_distill3.py:1158-1170
+    phi    = features @ weight.T + bias                      # affinities to the S cached samples
+    logits = (phi @ labels) / sample_lens [/ 2]              # per class
+    logits_text = features @ text_weight.T
+as two MFMA GEMMs behind ``hg_load_cache`` / ``hg_cache_logits``.  Inference only; CPU tensors raise
+``RuntimeError`` (there is no CPU fallback).
+"""
+import itertools
+import threading
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+_slots = itertools.cycle(range(8))          # HG_MAX_CACHE_SLOTS
+_lock = threading.Lock()
+
+
+def _dev_index(t: torch.Tensor) -> int:
+    if t.device.type != "cuda":
+        raise RuntimeError("hoigen_amd: the cache model runs only on a HIP device (there is no CPU fallback)")
+    return t.device.index if t.device.index is not None else torch.cuda.current_device()
+
+
+class CacheLogits:
+    """``CacheLogits(weight [S,K], bias [S] | None, labels [S,C] | None, sample_lens [C] | None, post_div)``.
+
+    ``__call__(features [R,K]) -> [R,C]`` = ``((features @ weight.T + bias) @ labels) / sample_lens / post_div``
+    (``post_div=2`` for the human-object branch, upt…:1167); without ``labels`` it is the linear map
+    ``features @ weight.T + bias -> [R,S]`` (``logits_text``, upt…:1170).  The tensors are copied into the native
+    context at construction (call ``update`` after changing them)."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None,
+                 sample_lens: Optional[torch.Tensor] = None, post_div: float = 1.0):
+        with _lock:
+            self.slot = next(_slots)
+        self.post_div = float(post_div)
+        self.update(weight, bias, labels, sample_lens)
+
+    def update(self, weight, bias=None, labels=None, sample_lens=None):
+        self.device = _dev_index(weight)
+        if (labels is None) != (sample_lens is None):
+            raise ValueError("labels and sample_lens go together")
+        S, K = weight.shape
+        self.S, self.K = int(S), int(K)
+        self.C = int(labels.shape[1]) if labels is not None else 0
+        keep = [t.detach().float().contiguous() if t is not None else None for t in (weight, bias, labels, sample_lens)]
+        w = _lib.hg_cache_weights()
+        w.weight, w.bias, w.labels, w.sample_lens = (_lib.tensor(t) for t in keep)
+        w.S, w.K, w.C, w.post_div = self.S, self.K, self.C, self.post_div
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().hg_load_cache(_lib.ctx(self.device), self.slot, _lib.C.byref(w))
+        _lib.check(self.device, rc, "hg_load_cache")
+
+    def __call__(self, features: torch.Tensor) -> torch.Tensor:
+        if _dev_index(features) != self.device:
+            raise RuntimeError("features are on a different device than the cache model")
+        if features.dim() != 2 or features.shape[1] != self.K:
+            raise ValueError(f"features must be [R, {self.K}]")
+        f = features.detach().float().contiguous()
+        n_out = self.C if self.C else self.S
+        out = torch.empty(f.shape[0], n_out, dtype=torch.float32, device=f.device)
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().hg_cache_logits(_lib.ctx(self.device), self.slot, f.data_ptr(), f.shape[0], out.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream)
+        _lib.check(self.device, rc, "hg_cache_logits")
+        return out

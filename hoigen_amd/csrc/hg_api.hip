@@ -79,6 +79,14 @@ struct Vae {
     std::vector<void*> owned;
 };
 
+struct Cache {
+    bool loaded = false, has_labels = false;
+    int S = 0, K = 0, C = 0, Sp = 0, Cp = 0;
+    half_t *w16 = nullptr, *lt16 = nullptr;   // [Sp,K] ; labels^T [Cp,Sp]
+    float *b = nullptr, *bias_c = nullptr, *scale = nullptr;   // [Sp] ; [Cp] bias @ labels ; [Cp] 1 / (lens * post_div)
+    std::vector<void*> owned;
+};
+
 struct Mlp {
     bool loaded = false;
     int in = 0, hid = 0, out = 0;
@@ -96,6 +104,7 @@ struct hg_ctx {
     Text text;
     Vae vae[HG_MAX_SLOTS];
     Mlp mlp[HG_MAX_SLOTS];
+    Cache cache[HG_MAX_CACHE_SLOTS];
     // workspace (grow-only)
     Buf x, h, qkv, att, fc, head16, tok32, small, i32, ad32, ad16, adkv, mr, stats, pre, pretab;
     int max_chunk_img = 256;
@@ -553,6 +562,7 @@ void hg_destroy(hg_ctx* c) {
     free_all(c->text.owned);
     for (auto& v : c->vae) free_all(v.owned);
     for (auto& m : c->mlp) free_all(m.owned);
+    for (auto& m : c->cache) free_all(m.owned);
     Buf* bufs[] = {&c->x, &c->h, &c->qkv, &c->att, &c->fc, &c->head16, &c->tok32, &c->small, &c->i32,
                    &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->stats, &c->pre, &c->pretab};
     for (Buf* b : bufs)
@@ -850,6 +860,128 @@ int hg_load_mlp(hg_ctx* c, int slot, const hg_mlp_weights* w) {
     if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
     HG_HIP(hipDeviceSynchronize());
     m.loaded = true;
+    return HG_OK;
+}
+
+// ---- cache-model logits -----------------------------------------------------------------
+static int to_host_f32(hg_ctx* c, const hg_tensor& t, size_t n, std::vector<float>& out, const char* name) {
+    std::vector<void*> sc;
+    float* d = nullptr;
+    int rc = as_f32(c, sc, t, n, &d, name);
+    if (rc) { free_all(sc); return rc; }
+    out.resize(n);
+    hipError_t e = hipMemcpy(out.data(), d, n * 4, hipMemcpyDeviceToHost);
+    free_all(sc);
+    return e == hipSuccess ? HG_OK : fail(c, HG_ERR_HIP, "hipMemcpy D2H failed for %s", name);
+}
+
+static int upload_f32(hg_ctx* c, std::vector<void*>& owned, const std::vector<float>& v, float** out) {
+    void* p;
+    int rc = dev_alloc(c, owned, v.size() * 4, &p);
+    if (rc) return rc;
+    HG_HIP(hipMemcpy(p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    *out = (float*)p;
+    return HG_OK;
+}
+
+int hg_load_cache(hg_ctx* c, int slot, const hg_cache_weights* w) {
+    if (!c || !w || slot < 0 || slot >= HG_MAX_CACHE_SLOTS) return HG_ERR_INVALID;
+    HG_HIP(hipSetDevice(c->device));
+    Cache& m = c->cache[slot];
+    free_all(m.owned);
+    m = Cache{};
+    m.S = w->S; m.K = w->K; m.C = w->C; m.has_labels = w->labels.ptr != nullptr;
+    if (m.S <= 0 || m.K <= 0 || m.K % 64 || (m.has_labels && m.C <= 0))
+        return fail(c, HG_ERR_INVALID, "cache model: S > 0, K %% 64 == 0 (got S=%d K=%d C=%d)", m.S, m.K, m.C);
+    m.Sp = (int)rup(m.S, 128);
+    m.Cp = m.has_labels ? (int)rup(m.C, 128) : 0;
+    // weight rows padded with zeros to a multiple of 128 (the GEMM's N granularity)
+    int rc = dev_alloc(c, m.owned, (size_t)m.Sp * m.K * 2, (void**)&m.w16);
+    if (rc) return rc;
+    HG_HIP(hipMemset(m.w16, 0, (size_t)m.Sp * m.K * 2));
+    if (!w->weight.ptr) return fail(c, HG_ERR_INVALID, "missing tensor cache weight");
+    if (w->weight.dtype == HG_F16) HG_HIP(hipMemcpy(m.w16, w->weight.ptr, (size_t)m.S * m.K * 2, hipMemcpyDeviceToDevice));
+    else HG_HIP(launch_f32_to_f16((const float*)w->weight.ptr, m.w16, (size_t)m.S * m.K, 0));
+    std::vector<float> bias(m.Sp, 0.f);
+    if (w->bias.ptr) {
+        std::vector<float> b;
+        rc = to_host_f32(c, w->bias, m.S, b, "cache bias");
+        if (rc) return rc;
+        for (int i = 0; i < m.S; ++i) bias[i] = b[i];
+    }
+    if (!m.has_labels) {
+        rc = upload_f32(c, m.owned, bias, &m.b);
+        if (rc) return rc;
+    } else {
+        // (f W^T + b) L / lens / post_div = ((f W^T) L + b L) * scale: the bias term is a per-class constant
+        // (kept in fp32; phi = f W^T alone goes through fp16 for the second MFMA GEMM)
+        std::vector<float> lab, lens;
+        rc = to_host_f32(c, w->labels, (size_t)m.S * m.C, lab, "cache labels");
+        if (!rc) rc = to_host_f32(c, w->sample_lens, m.C, lens, "cache sample_lens");
+        if (rc) return rc;
+        std::vector<float> lt((size_t)m.Cp * m.Sp, 0.f), bc(m.Cp, 0.f), sc(m.Cp, 0.f);
+        for (int cc = 0; cc < m.C; ++cc) {
+            double acc = 0.0;
+            for (int i = 0; i < m.S; ++i) {
+                const float v = lab[(size_t)i * m.C + cc];
+                lt[(size_t)cc * m.Sp + i] = v;
+                acc += (double)bias[i] * v;
+            }
+            bc[cc] = (float)acc;
+            sc[cc] = 1.0f / (lens[cc] * (w->post_div != 0.f ? w->post_div : 1.f));
+        }
+        float* lt32 = nullptr;
+        std::vector<void*> scratch;
+        rc = upload_f32(c, scratch, lt, &lt32);
+        if (!rc) rc = dev_alloc(c, m.owned, lt.size() * 2, (void**)&m.lt16);
+        if (!rc) { hipError_t e = launch_f32_to_f16(lt32, m.lt16, lt.size(), 0); if (e != hipSuccess) rc = HG_ERR_HIP; }
+        if (!rc) { hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) rc = HG_ERR_HIP; }
+        free_all(scratch);
+        if (!rc) rc = upload_f32(c, m.owned, bc, &m.bias_c);
+        if (!rc) rc = upload_f32(c, m.owned, sc, &m.scale);
+        if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
+    }
+    HG_HIP(hipDeviceSynchronize());
+    m.loaded = true;
+    return HG_OK;
+}
+
+int hg_cache_logits(hg_ctx* c, int slot, const float* feats, int R, float* out, void* stream) {
+    if (!c || slot < 0 || slot >= HG_MAX_CACHE_SLOTS) return HG_ERR_INVALID;
+    Cache& m = c->cache[slot];
+    if (!m.loaded) return fail(c, HG_ERR_NOT_LOADED, "cache slot %d not loaded", slot);
+    if (R == 0) return HG_OK;
+    if (R < 0 || !feats || !out) return fail(c, HG_ERR_INVALID, "bad arguments to cache_logits");
+    hipStream_t s = (hipStream_t)stream;
+    HG_HIP(hipSetDevice(c->device));
+    for (int r0 = 0; r0 < R; r0 += c->max_chunk_rows) {
+        const int Rc = (R - r0 < c->max_chunk_rows) ? R - r0 : c->max_chunk_rows;
+        const size_t Rp = rup(Rc, 256);
+        const int Np = m.has_labels ? m.Cp : m.Sp, Nout = m.has_labels ? m.C : m.S;
+        int rc = ensure(c, c->h, Rp * m.K * 2);
+        if (!rc) rc = ensure(c, c->att, Rp * m.Sp * 2);
+        if (!rc) rc = ensure(c, c->x, Rp * Np * 4);
+        if (rc) return rc;
+        half_t* f16 = (half_t*)c->h.p;
+        half_t* phi = (half_t*)c->att.p;
+        float* tmp = (float*)c->x.p;
+        HG_HIP(launch_f32_to_f16(feats + (size_t)r0 * m.K, f16, (size_t)Rc * m.K, s));
+        GemmArgs g{};
+        g.A = f16; g.lda = m.K; g.W = m.w16; g.M = Rc; g.N = m.Sp; g.K = m.K;
+        if (!m.has_labels) {
+            g.bias = m.b; g.out = tmp; g.ldc = m.Sp;
+            HG_HIP(gemm(c, EPI_BIAS_F32, g, s));
+        } else {
+            g.bias = nullptr; g.out = phi; g.ldc = m.Sp;
+            HG_HIP(gemm(c, EPI_BIAS_F16, g, s));
+            HG_HIP(hipMemsetAsync(tmp, 0, (size_t)Rc * m.Cp * 4, s));
+            g = GemmArgs{};
+            g.A = phi; g.lda = m.Sp; g.W = m.lt16; g.bias = m.bias_c; g.pos = m.scale; g.out = tmp; g.ldc = m.Cp;
+            g.M = Rc; g.N = m.Cp; g.K = m.Sp;
+            HG_HIP(gemm(c, EPI_SCALE_RESID_F32, g, s));          // 0 + (phi L + b L) * scale
+        }
+        HG_HIP(launch_copy_cols(tmp, Np, out + (size_t)r0 * Nout, Rc, Nout, s));
+    }
     return HG_OK;
 }
 

@@ -425,7 +425,18 @@ hipError_t launch_copy_rows(const float* x, float* out, int B, int row_stride, i
     hipLaunchKernelGGL(copy_rows_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, x, out, B, row_stride, D);
     return hipGetLastError();
 }
-
+// first N columns of a [R, ld] matrix -> dense [R, N]
+__global__ void copy_cols_kernel(const float* __restrict__ x, int ld, float* __restrict__ out, int R, int N) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)R * N) return;
+    const int r = (int)(i / N), j = (int)(i - (size_t)r * N);
+    out[i] = x[(size_t)r * ld + j];
+}
+hipError_t launch_copy_cols(const float* x, int ld, float* out, int R, int N, hipStream_t s) {
+    if (R <= 0 || N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)(((size_t)R * N + 255) / 256)), dim3(256), 0, s, x, ld, out, R, N);
+    return hipGetLastError();
+}
 
 // ---- LayerNorm folding support ------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void fold_ln_kernel(const half_t* __restrict__ w16, const float* __restrict__ gamma,

@@ -102,6 +102,8 @@ hipError_t launch_vae_loss(const float* recon, const float* x, const float* mean
 hipError_t launch_split_global_local(const float* tok, float* glob, float* local, int B, int L, int E,
                                      hipStream_t s);
 hipError_t launch_copy_rows(const float* x, float* out, int B, int row_stride, int D, hipStream_t s);
+// first N columns of a [R, ld] fp32 matrix -> dense [R, N]
+hipError_t launch_copy_cols(const float* x, int ld, float* out, int R, int N, hipStream_t s);
 // ---- LayerNorm folding support (DESIGN.md §4 "LayerNorm folded into the GEMMs")
 // W16 [N,K], gamma/beta [K], bias [N]  ->  Wf16 = fp16(W * gamma), cs[n] = sum_k float(Wf16[n][k]), bf[n] = bias[n] + sum_k W[n][k] * beta[k]
 hipError_t launch_fold_ln(const half_t* w16, const float* gamma, const float* beta, const float* bias, half_t* wf16,

@@ -183,6 +183,21 @@ int hg_assemble_prompts(hg_ctx*, const float* prefix, const float* suffix, const
                         int D, float* prompts, void* stream);
 /* x / x.norm(dim=-1, keepdim=True) (main_coop_vae.py:438,466); in == out allowed. */
 int hg_l2_normalize(hg_ctx*, const float* x, int R, int D, float* out, void* stream);
+/* Cache-model (Tip-adapter) logits on the embeddings (SURVEY.md 8f-3;
+ * upt_tip_cache_model_free_finetune_distill3.py:1158-1170):
+ *   phi = f @ weight.T + bias ; logits = (phi @ labels) / sample_lens / post_div          -> [R, C]
+ * weight [S,K] (cached, L2-normalised embeddings; K % 64 == 0), bias [S] (nullable = 0), labels [S,C] multi-hot
+ * (values exactly representable in fp16), sample_lens [C], post_div (2 for the HO branch, else 1).
+ * With labels.ptr == NULL the slot is a plain linear map (logits_text = f @ weight.T + bias -> [R, S]). */
+#define HG_MAX_CACHE_SLOTS 8
+typedef struct {
+    hg_tensor weight, bias, labels, sample_lens;
+    int32_t S, K, C;
+    float post_div;
+} hg_cache_weights;
+int hg_load_cache(hg_ctx*, int slot, const hg_cache_weights* w);
+int hg_cache_logits(hg_ctx*, int slot, const float* feats, int R, float* out, void* stream);
+
 /* Crop pre-processing in front of encode_image: for every box of one image
  *   image.crop(box)                       pre_images/crop_images.py:204-219 (PIL: zeros outside the image)
  *   [expand2square(crop, background)]     utils_tip_cache_and_union_finetune.py:201-212  (pad_square != 0)

@@ -1,0 +1,85 @@
+"""Cache-model (Tip-adapter) logits: oracle vs the reference's own lines, HIP vs both."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from cache_cases import CASES, cache_case  # noqa: E402
+from oracle import cache_oracle as co  # noqa: E402
+
+G = os.path.join(ROOT, "tests", "golden", "g7_cache.npz")
+TOL = 1e-3
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    rows = np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(b, axis=1), 1e-30)
+    return np.linalg.norm(a - b) / np.linalg.norm(b), rows.max()
+
+
+def oracle_outputs(t):
+    ho = co.cache_logits(np.concatenate([t["human"], t["object"]], 1), t["w_ho"], t["b_ho"], t["label"], t["lens"], 2.0)
+    u = co.cache_logits(t["union"], t["w_u"], t["b_u"], t["label"], t["lens"])
+    return ho, u, co.linear_logits(t["union"], t["w_text"])
+
+
+def test_oracle_matches_reference_lines():
+    g = dict(np.load(G))
+    for case in range(len(CASES)):
+        for got, name in zip(oracle_outputs(cache_case(case)), ("logits_cache_HO", "logits_cache_U", "logits_text")):
+            whole, worst = rel(got, g[f"{name}_{case}"])
+            assert whole <= 1e-6 and worst <= 1e-5, (case, name, whole, worst)
+
+
+def test_facade_errors_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from hoigen_amd.cache_model import CacheLogits
+    with pytest.raises(RuntimeError, match="HIP device"):
+        CacheLogits(torch.zeros(4, 64))
+
+
+@pytest.mark.gpu
+def test_hip_cache_logits_vs_reference():
+    from hoigen_amd.cache_model import CacheLogits
+    g = dict(np.load(G))
+    dev = torch.device("cuda:0")
+    for case in range(len(CASES)):
+        t = {k: torch.from_numpy(v).to(dev) for k, v in cache_case(case).items()}
+        ho = CacheLogits(t["w_ho"], t["b_ho"], t["label"], t["lens"], post_div=2.0)(torch.cat([t["human"], t["object"]], -1))
+        u = CacheLogits(t["w_u"], t["b_u"], t["label"], t["lens"])(t["union"])
+        tx = CacheLogits(t["w_text"])(t["union"])
+        R, S, C, D = CASES[case]
+        assert ho.shape == (R, C) and u.shape == (R, C) and tx.shape == (R, C) and ho.dtype == torch.float32
+        for got, name in ((ho, "logits_cache_HO"), (u, "logits_cache_U"), (tx, "logits_text")):
+            whole, worst = rel(got.cpu().numpy(), g[f"{name}_{case}"])
+            print(f"\ncase {case} {name}: rel-L2 {whole:.2e} (worst row {worst:.2e})")
+            assert whole <= TOL and worst <= TOL, (case, name, whole, worst)
+
+
+@pytest.mark.gpu
+def test_hip_cache_logits_ragged_and_update():
+    """Odd sizes (S, C not multiples of 128; one row; many rows -> chunks), empty batch, weight update."""
+    from hoigen_amd.cache_model import CacheLogits
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(3)
+    S, C, K = 77, 24, 64
+    w = rng.randn(S, K).astype(np.float32); b = rng.randn(S).astype(np.float32)
+    lab = (rng.rand(S, C) < 0.1).astype(np.float32); lens = np.maximum(lab.sum(0), 1).astype(np.float32)
+    m = CacheLogits(*(torch.from_numpy(a).to(dev) for a in (w, b, lab, lens)))
+    for R in (1, 130, 40000):
+        f = rng.randn(R, K).astype(np.float32)
+        whole, worst = rel(m(torch.from_numpy(f).to(dev)).cpu().numpy(), co.cache_logits(f, w, b, lab, lens))
+        assert whole <= TOL, (R, whole)
+    assert m(torch.zeros(0, K, device=dev)).shape == (0, C)
+    w2 = rng.randn(S, K).astype(np.float32)
+    m.update(torch.from_numpy(w2).to(dev), torch.from_numpy(b).to(dev), torch.from_numpy(lab).to(dev), torch.from_numpy(lens).to(dev))
+    f = rng.randn(9, K).astype(np.float32)
+    assert rel(m(torch.from_numpy(f).to(dev)).cpu().numpy(), co.cache_logits(f, w2, b, lab, lens))[0] <= TOL
+    with pytest.raises(ValueError):
+        m(torch.zeros(3, K + 64, device=dev))
