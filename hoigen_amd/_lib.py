@@ -108,6 +108,7 @@ SIGNATURES = {
     "hg_assemble_prompts": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "hg_l2_normalize": (_I, [_P, _P, _I, _I, _P, _P]),
     "hg_vae_loss": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
+    "hg_roi_align": (_I, [_P, _P, _I, _I, _I, _P, _I, C.c_float, _I, _P, _P, _P]),
     "hg_load_cache": (_I, [_P, _I, _P]),
     "hg_cache_logits": (_I, [_P, _I, _P, _I, _P, _P]),
     "hg_preprocess_crops": (_I, [_P, _P, _I, _I, _P, _I, _I, _I, C.c_uint32, _P, _P, _P]),

@@ -863,6 +863,17 @@ int hg_load_mlp(hg_ctx* c, int slot, const hg_mlp_weights* w) {
     return HG_OK;
 }
 
+int hg_roi_align(hg_ctx* c, const float* feat, int C, int H, int W, const float* boxes, int n, float spatial_scale,
+                 int P, float* out_pooled, float* out_mean, void* stream) {
+    if (!c) return HG_ERR_INVALID;
+    if (n == 0) return HG_OK;
+    if (!feat || !boxes || n < 0 || C <= 0 || H <= 0 || W <= 0 || P <= 0 || (!out_pooled && !out_mean))
+        return fail(c, HG_ERR_INVALID, "hg_roi_align: bad arguments");
+    HG_HIP(hipSetDevice(c->device));
+    HG_HIP(launch_roi_align(feat, C, H, W, boxes, n, spatial_scale, P, out_pooled, out_mean, (hipStream_t)stream));
+    return HG_OK;
+}
+
 // ---- cache-model logits -----------------------------------------------------------------
 static int to_host_f32(hg_ctx* c, const hg_tensor& t, size_t n, std::vector<float>& out, const char* name) {
     std::vector<void*> sc;

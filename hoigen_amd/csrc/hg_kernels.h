@@ -122,6 +122,11 @@ hipError_t launch_preprocess(const uint8_t* img, int H, int W, const int32_t* he
                              const int32_t* tab_off, int n, int n_px, int max_rows, uint8_t* tmp, float* out,
                              uint8_t* out_u8, hipStream_t s);
 
+// RoI-align (torchvision semantics, aligned=True, sampling_ratio=-1) of feat [C,H,W] for boxes [n,4] (device):
+// out_pooled [n,C,P,P] and/or out_mean [n,C] (= .flatten(2).mean(-1)); either may be null
+hipError_t launch_roi_align(const float* feat, int C, int H, int W, const float* boxes, int n, float spatial_scale,
+                            int P, float* out_pooled, float* out_mean, hipStream_t s);
+
 // ---- adapter (variant C) --------------------------------------------------------------------
 struct AdapterDev {      // device pointers, all fp32 except the two MFMA operands
     const half_t* down_w;   // [d, D] fp16

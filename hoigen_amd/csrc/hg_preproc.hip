@@ -163,3 +163,62 @@ hipError_t launch_preprocess(const uint8_t* img, int H, int W, const int32_t* he
 }
 
 }  // namespace hg
+
+// ---- RoI-align over the local feature map ------------------------------------------------
+// torchvision.ops.roi_align(feat[1,C,H,W], [boxes], (P,P), spatial_scale, sampling_ratio=-1, aligned=True) and the
+// `.flatten(2).mean(-1)` that follows it (upt_tip_cache_model_free_finetune_distill3.py:1026-1037).
+// One workgroup per RoI, one lane per channel; the P*P bins are walked in order so that the optional full
+// output [n,C,P,P] and the per-RoI mean [n,C] come out of the same pass.  fp32 throughout, in the operation
+// order of torchvision's CPU kernel (pre-computed bilinear weights w1..w4 = hy*hx, hy*lx, ly*hx, ly*lx).
+namespace hg {
+
+__global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict__ feat, int C, int H, int W,
+                                                        const float* __restrict__ boxes, float spatial_scale, int P,
+                                                        float* __restrict__ out_pooled, float* __restrict__ out_mean) {
+#pragma clang fp contract(off)
+    const int n = blockIdx.x;
+    const float* b = boxes + 4 * (size_t)n;
+    const float sw = b[0] * spatial_scale - 0.5f, sh = b[1] * spatial_scale - 0.5f;
+    const float ew = b[2] * spatial_scale - 0.5f, eh = b[3] * spatial_scale - 0.5f;
+    const float rw = ew - sw, rh = eh - sh;
+    const float bh = rh / (float)P, bw = rw / (float)P;
+    const int gh = (int)ceilf(rh / (float)P), gw = (int)ceilf(rw / (float)P);
+    const float count = (float)(gh * gw > 1 ? gh * gw : 1);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float* f = feat + (size_t)c * H * W;
+        float total = 0.f;
+        for (int ph = 0; ph < P; ++ph)
+            for (int pw = 0; pw < P; ++pw) {
+                float acc = 0.f;
+                for (int iy = 0; iy < gh; ++iy) {
+                    float y = sh + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+                    for (int ix = 0; ix < gw; ++ix) {
+                        float x = sw + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+                        float yy = y;
+                        if (yy < -1.0f || yy > (float)H || x < -1.0f || x > (float)W) continue;
+                        if (yy <= 0.f) yy = 0.f;
+                        if (x <= 0.f) x = 0.f;
+                        int yl = (int)yy, xl = (int)x, yh, xh;
+                        if (yl >= H - 1) { yh = yl = H - 1; yy = (float)yl; } else yh = yl + 1;
+                        if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+                        const float ly = yy - (float)yl, lx = x - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
+                        acc += (hy * hx) * f[yl * W + xl] + (hy * lx) * f[yl * W + xh] + (ly * hx) * f[yh * W + xl] +
+                               (ly * lx) * f[yh * W + xh];
+                    }
+                }
+                acc /= count;
+                if (out_pooled) out_pooled[(((size_t)n * C + c) * P + ph) * P + pw] = acc;
+                total += acc;
+            }
+        if (out_mean) out_mean[(size_t)n * C + c] = total / (float)(P * P);
+    }
+}
+
+hipError_t launch_roi_align(const float* feat, int C, int H, int W, const float* boxes, int n, float spatial_scale,
+                            int P, float* out_pooled, float* out_mean, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(roi_align_kernel, dim3(n), dim3(256), 0, s, feat, C, H, W, boxes, spatial_scale, P, out_pooled, out_mean);
+    return hipGetLastError();
+}
+
+}  // namespace hg

@@ -183,6 +183,14 @@ int hg_assemble_prompts(hg_ctx*, const float* prefix, const float* suffix, const
                         int D, float* prompts, void* stream);
 /* x / x.norm(dim=-1, keepdim=True) (main_coop_vae.py:438,466); in == out allowed. */
 int hg_l2_normalize(hg_ctx*, const float* x, int R, int D, float* out, void* stream);
+/* RoI-align over the variant-C local feature map (SURVEY.md 8f-4;
+ * upt_tip_cache_model_free_finetune_distill3.py:1026-1037): torchvision.ops.roi_align(feat[None], [boxes],
+ * output_size=(P,P), spatial_scale, sampling_ratio=-1, aligned=True) -> out_pooled [n,C,P,P] (nullable) and its
+ * .flatten(2).mean(-1) -> out_mean [n,C] (nullable).  feat: fp32 [C,H,W] (one image of hg_encode_image_prior's
+ * out_local), boxes: fp32 [n,4] (x1,y1,x2,y2) in image pixels; all device pointers. */
+int hg_roi_align(hg_ctx*, const float* feat, int C, int H, int W, const float* boxes, int n, float spatial_scale,
+                 int P, float* out_pooled, float* out_mean, void* stream);
+
 /* Cache-model (Tip-adapter) logits on the embeddings (SURVEY.md 8f-3;
  * upt_tip_cache_model_free_finetune_distill3.py:1158-1170):
  *   phi = f @ weight.T + bias ; logits = (phi @ labels) / sample_lens / post_div          -> [R, C]
