@@ -51,7 +51,7 @@ namespace hg {
 #define SEG_E(k) do {} while (0)
 #endif
 
-template <int MF, int EPI>
+template <int MF, int EPI, bool PH2>
 __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int tiles_n, const int n_tiles,
                                                     const unsigned a_bytes, const int mode, const int gsz) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins (buffer resources, LDS DMA): host sees just the stub
@@ -288,9 +288,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     if (S > 1) {
         ld_advance();
         issue_A(0, 0, GA); issue_W(0, 0, GB); issue_W(1, 0, GB);
-        wait_vm<N1>();                     // A0, W0 of position 0 landed
+        if constexpr (PH2) wait_vm<2 * GA + 2 * GB>();   // A0, W0, W1 of position 0 landed
+        else wait_vm<N1>();                // A0, W0 of position 0 landed
     } else {
-        wait_vm<GA + GB>();
+        if constexpr (PH2) wait_vm<GA>();
+        else wait_vm<GA + GB>();
     }
     barrier_raw();
     // Stagger: waves 4-7 (the second wave of every SIMD) run one barrier interval behind waves 0-3, so a
@@ -314,6 +316,63 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             const bool more = g + 2 < S;          // a K-tile two positions ahead exists
             const bool post = r > 0;               // epilogue stores of the previous tile may still be pending
             const bool xl = XPRE && kt == nk - 1;  // residual rows are fetched during the last K-tile
+            if constexpr (PH2) {
+            // Two phases per K-tile (32 MFMAs per segment, half the barriers):
+            //   PA: fetch A0 W0 W1 (t); refill A1(t+1);               wait -> A1(t) landed;        quadrants (0,0) (0,1)
+            //   PB: fetch A1 (t);       refill A0 W0 W1 (t+2);         wait -> A0 W0 W1 (t+1) landed; quadrants (1,1) (1,0)
+            // both waits leave NP = 2GA+2GB DMA instructions (64 KiB per CU) in flight
+            constexpr int NP = 2 * GA + 2 * GB;
+            read_A(0, buf);
+            read_W(I0{}, buf);
+            read_W(I1{}, buf);
+            if constexpr (LNC) {
+                if (kt == nk - 2 && lane < BM / 16)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsM, (HG_LDS void*)(smem + MR_OFF + wave * BM), 16, lane * 16,
+                                                             (m0 + wave * (BM / 8)) * 8, 0, 0);
+            }
+            if (g + 1 < S) issue_A(1, 0, GA);
+            if constexpr (XPRE) {
+                if (xl) {
+#pragma unroll
+                    for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+                        for (int f = 0; f < MF; ++f) {
+                            int m = m0 + ha * (BM / 2) + wm * MF * 16 + f * 16 + (lane & 15);
+                            m = m < p.M ? m : p.M - 1;
+#pragma unroll
+                            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                                for (int g2 = 0; g2 < 2; ++g2) {
+                                    const int n = n0 + hb * 128 + wn * 32 + g2 * 16 + 4 * (lane >> 4);
+                                    xres[ha][hb][f][g2] = *reinterpret_cast<const f32x4*>(
+                                        reinterpret_cast<const float*>(p.out) + (size_t)m * p.ldc + n);
+                                }
+                        }
+                }
+            }
+            SEG_B(0);
+            if (!more) wait_vm<0>();
+            else if (xl) wait_vm<NP + R>();
+            else if (post && kt == 0) wait_vm<NP + E>();
+            else wait_vm<NP>();
+            SEG_E(0);
+            sync_fetch();
+            mma(I0{}, I0{});
+            mma(I0{}, I1{});
+            sync_mma();
+            read_A(1, buf);
+            if (more) { ld_advance(); issue_A(0, 0, GA); issue_W(0, 0, GB); issue_W(1, 0, GB); }
+            SEG_B(0);
+            if (!more) wait_vm<0>();
+            else if (xl) wait_vm<NP + R>();
+            else if (post && kt == 0) wait_vm<NP + E>();
+            else wait_vm<NP>();
+            SEG_E(0);
+            sync_fetch();
+            mma(I1{}, I1{});
+            mma(I1{}, I0{});
+            sync_mma();
+            } else {
             // ---------------- P1: fetch A0(t), W0(t); refill A1(t+1); then quadrant (0,0)
             read_A(0, buf);
             read_W(I0{}, buf);
@@ -384,6 +443,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             sync_fetch();
             mma(I1{}, I0{});
             sync_mma();
+                    }
         }
         // ---------------- epilogue of tile r (the ring keeps prefetching the next tile meanwhile)
         SEG_B(7);
@@ -499,7 +559,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
 #endif
 }
 
-template <int MF, int EPI>
+template <int MF, int EPI, bool PH2 = false>
 static hipError_t launch_ring_t(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = 64 * MF;
     constexpr int RING = 2 * (2 * MF * 4096 + 2 * 16384);
@@ -509,7 +569,7 @@ static hipError_t launch_ring_t(const GemmArgs& a, hipStream_t s) {
     static bool attr_set = false;
     static int n_cu = 256;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring<MF, EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring<MF, EPI, PH2>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         int dev = 0;
@@ -543,7 +603,7 @@ static hipError_t launch_ring_t(const GemmArgs& a, hipStream_t s) {
         hipMemsetAsync(d, 0, n * 8, s);
         GemmArgs b = a;
         b.dbg = d;
-        hipLaunchKernelGGL((gemm_ring<MF, EPI>), dim3(grid), dim3(512), LDS, s, b, tiles_n, n_tiles, (unsigned)a_bytes, mode, gsz);
+        hipLaunchKernelGGL((gemm_ring<MF, EPI, PH2>), dim3(grid), dim3(512), LDS, s, b, tiles_n, n_tiles, (unsigned)a_bytes, mode, gsz);
         hipStreamSynchronize(s);
         unsigned long long* h = (unsigned long long*)malloc(n * 8);
         hipMemcpy(h, d, n * 8, hipMemcpyDeviceToHost);
@@ -563,7 +623,7 @@ static hipError_t launch_ring_t(const GemmArgs& a, hipStream_t s) {
         return hipGetLastError();
     }
 #endif
-    hipLaunchKernelGGL((gemm_ring<MF, EPI>), dim3(grid), dim3(512), LDS, s, a, tiles_n, n_tiles, (unsigned)a_bytes, mode, gsz);
+    hipLaunchKernelGGL((gemm_ring<MF, EPI, PH2>), dim3(grid), dim3(512), LDS, s, a, tiles_n, n_tiles, (unsigned)a_bytes, mode, gsz);
     return hipGetLastError();
 }
 
@@ -591,9 +651,11 @@ hipError_t launch_gemm_ring(int epi, const GemmArgs& a, hipStream_t s) {
     static const int force_big = []() { const char* e = getenv("HG_RING_BIG"); return e ? atoi(e) : 0; }();
     const bool big = force_big == 1 ? true : (force_big == 2 || force_big == 3) ? false : (t256 >= 256 && (double)t256 / (rounds * 256.0) >= 0.9);
     if (!big && force_big != 3 && !lnc && gemm_ring2_ok(a)) return launch_gemm_ring2(epi, a, s);   // 128x256, two-phase
+    // 256x256 tiles run two phases per K-tile (32 MFMAs per segment): -4..8 % vs four phases; HG_RING_PH2=0 = four
+    static const bool ph2 = []() { const char* e = getenv("HG_RING_PH2"); return e ? atoi(e) != 0 : true; }();
 #define HG_RING(E)                                                         \
     case E:                                                                \
-        return big ? launch_ring_t<4, E>(a, s) : launch_ring_t<2, E>(a, s)
+        return big ? (ph2 ? launch_ring_t<4, E, true>(a, s) : launch_ring_t<4, E, false>(a, s)) : launch_ring_t<2, E, false>(a, s)
     switch (epi) {
         HG_RING(EPI_BIAS_F16);
         HG_RING(EPI_BIAS_QGELU_F16);
