@@ -106,7 +106,7 @@ struct hg_ctx {
     Mlp mlp[HG_MAX_SLOTS];
     Cache cache[HG_MAX_CACHE_SLOTS];
     // workspace (grow-only)
-    Buf x, h, qkv, att, fc, head16, tok32, small, i32, ad32, ad16, adkv, mr, stats, pre, pretab;
+    Buf x, h, qkv, att, fc, head16, tok32, small, i32, ad32, ad16, adkv, mr, mu, stats, pre, pretab;
     int max_chunk_img = 256;
     int max_chunk_txt = 640;
     int max_chunk_rows = 32768;
@@ -418,7 +418,7 @@ bool ln_fuse_ok(hg_ctx* c, int M, int D) {
     g.N = 4 * D; g.ldc = 4 * D;
     if (!gemm_ln_ok(EPI_LN_BIAS_QGELU_F16, g)) return false;
     GemmArgs r{};
-    r.out2 = (half_t*)&dummy; r.stats = &dummy; r.stats_ld = 4 * (D / 256); r.M = M; r.N = D; r.ldc = D;
+    r.out2 = (half_t*)&dummy; r.stats = &dummy; r.mu = &dummy; r.stats_ld = 4 * (D / 256); r.M = M; r.N = D; r.ldc = D;
     r.K = D; r.lda = D;
     if (!gemm_ln_ok(EPI_RESID_LN_F32, r)) return false;
     r.K = 4 * D; r.lda = 4 * D;
@@ -437,14 +437,17 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
     const bool fuse = ln_fold && !adapters && ln_fuse_ok(c, M, D);
     const int sld = 4 * (D / 256);
     float* mr = nullptr;
+    float* mu = nullptr;
     float* stats = nullptr;
     if (fuse) {
         int rc = ensure(c, c->mr, rup(M, 256) * 2 * 4);
+        if (!rc) rc = ensure(c, c->mu, rup(M, 256) * 4);
         if (!rc) rc = ensure(c, c->stats, rup(M, 256) * (size_t)sld * 2 * 4);
         if (rc) return rc;
         mr = (float*)c->mr.p;
+        mu = (float*)c->mu.p;
         stats = (float*)c->stats.p;
-        HG_HIP(launch_rowstats_cast(x, h, mr, M, D, s));
+        HG_HIP(launch_rowstats_cast(x, h, mr, mu, M, D, s));
     }
     for (size_t i = 0; i < blocks.size(); ++i) {
         const BlockW& b = blocks[i];
@@ -466,9 +469,9 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         g = GemmArgs{};
         g.A = att; g.lda = D; g.W = b.w_out; g.bias = b.b_out; g.out = x; g.ldc = D; g.M = M; g.N = D; g.K = D;
         if (fuse) {
-            g.out2 = h; g.stats = stats; g.stats_ld = sld;
+            g.out2 = h; g.stats = stats; g.stats_ld = sld; g.mu = mu;
             HG_HIP(gemm(c, EPI_RESID_LN_F32, g, s));
-            HG_HIP(launch_finalize_stats(stats, mr, M, sld, 64, s));
+            HG_HIP(launch_finalize_stats(stats, mr, mu, M, sld, 64, s));
         } else {
             HG_HIP(gemm(c, EPI_BIAS_RESID_F32, g, s));
         }
@@ -485,9 +488,9 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         g = GemmArgs{};
         g.A = fc; g.lda = 4 * D; g.W = b.w_proj; g.bias = b.b_proj; g.out = x; g.ldc = D; g.M = M; g.N = D; g.K = 4 * D;
         if (fuse && i + 1 < blocks.size()) {      // the last block is followed by ln_post / ln_final on selected rows
-            g.out2 = h; g.stats = stats; g.stats_ld = sld;
+            g.out2 = h; g.stats = stats; g.stats_ld = sld; g.mu = mu;
             HG_HIP(gemm(c, EPI_RESID_LN_F32, g, s));
-            HG_HIP(launch_finalize_stats(stats, mr, M, sld, 64, s));
+            HG_HIP(launch_finalize_stats(stats, mr, mu, M, sld, 64, s));
         } else {
             HG_HIP(gemm(c, EPI_BIAS_RESID_F32, g, s));
         }
@@ -564,7 +567,7 @@ void hg_destroy(hg_ctx* c) {
     for (auto& m : c->mlp) free_all(m.owned);
     for (auto& m : c->cache) free_all(m.owned);
     Buf* bufs[] = {&c->x, &c->h, &c->qkv, &c->att, &c->fc, &c->head16, &c->tok32, &c->small, &c->i32,
-                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->stats, &c->pre, &c->pretab};
+                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->stats, &c->pre, &c->pretab};
     for (Buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
@@ -705,7 +708,7 @@ int hg_profile_end(hg_ctx* c, double* avg_ms, int32_t* launches, double* flops_p
 int hg_workspace_bytes(hg_ctx* c, uint64_t* bytes) {
     if (!c || !bytes) return HG_ERR_INVALID;
     Buf* bufs[] = {&c->x, &c->h, &c->qkv, &c->att, &c->fc, &c->head16, &c->tok32, &c->small, &c->i32,
-                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->stats, &c->pre, &c->pretab};
+                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->stats, &c->pre, &c->pretab};
     uint64_t t = 0;
     for (Buf* b : bufs) t += b->bytes;
     *bytes = t;

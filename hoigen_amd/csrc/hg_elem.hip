@@ -468,7 +468,7 @@ hipError_t launch_fold_ln(const half_t* w16, const float* gamma, const float* be
 }
 
 __global__ __launch_bounds__(256) void rowstats_cast_kernel(const float* __restrict__ x, half_t* __restrict__ x16,
-                                                            float* __restrict__ mr, int M, int D) {
+                                                            float* __restrict__ mr, float* __restrict__ mu, int M, int D) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= M) return;
@@ -482,10 +482,6 @@ __global__ __launch_bounds__(256) void rowstats_cast_kernel(const float* __restr
         if (c < nc) {
             v[i] = xp[c];
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-            half4 h;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) h[e] = (half_t)v[i][e];
-            reinterpret_cast<half4*>(x16 + (size_t)r * D)[c] = h;
         }
     }
     const float mean = wave_sum(s) / (float)D;
@@ -494,29 +490,34 @@ __global__ __launch_bounds__(256) void rowstats_cast_kernel(const float* __restr
     for (int i = 0; i < LN_MAXC; ++i) {
         const int c = lane + 64 * i;
         if (c < nc) {
+            half4 h;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float d = v[i][e] - mean;
                 q += d * d;
+                h[e] = (half_t)d;
             }
+            reinterpret_cast<half4*>(x16 + (size_t)r * D)[c] = h;
         }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
     if (lane == 0) {
-        mr[2 * (size_t)r] = mean;
+        mr[2 * (size_t)r] = 0.f;
         mr[2 * (size_t)r + 1] = rstd;
+        mu[r] = mean;
     }
 }
-hipError_t launch_rowstats_cast(const float* x, half_t* x16, float* mr, int M, int D, hipStream_t s) {
+hipError_t launch_rowstats_cast(const float* x, half_t* x16, float* mr, float* mu, int M, int D, hipStream_t s) {
     if (M <= 0) return hipSuccess;
     if (D % 4 || D > 256 * LN_MAXC) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(rowstats_cast_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, x16, mr, M, D);
+    hipLaunchKernelGGL(rowstats_cast_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, x16, mr, mu, M, D);
     return hipGetLastError();
 }
 
 // partial statistics of row m over nt column groups of `gw` columns each: (sum_k, M2_k = sum (x - mean_k)^2);
 // combined with Chan's parallel-variance formula (no E[x^2] - mean^2 cancellation)
-__global__ void finalize_stats_kernel(const float* __restrict__ stats, float* __restrict__ mr, int M, int nt, int gw) {
+__global__ void finalize_stats_kernel(const float* __restrict__ stats, float* __restrict__ mr, float* __restrict__ mu,
+                                      int M, int nt, int gw) {
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
     const float* sp = stats + (size_t)m * nt * 2;
@@ -529,12 +530,13 @@ __global__ void finalize_stats_kernel(const float* __restrict__ stats, float* __
         const float d = sp[2 * t] / (float)gw - mean;
         m2 += sp[2 * t + 1] + (float)gw * d * d;
     }
-    mr[2 * (size_t)m] = mean;
+    mr[2 * (size_t)m] = mean - mu[m];             // the fp16 copy of this row was written as x - mu[m]
     mr[2 * (size_t)m + 1] = 1.0f / sqrtf(m2 / D + 1e-5f);
+    mu[m] = mean;                                 // centre for the next residual GEMM's copy
 }
-hipError_t launch_finalize_stats(const float* stats, float* mr, int M, int nt, int gw, hipStream_t s) {
+hipError_t launch_finalize_stats(const float* stats, float* mr, float* mu, int M, int nt, int gw, hipStream_t s) {
     if (M <= 0) return hipSuccess;
-    hipLaunchKernelGGL(finalize_stats_kernel, dim3((M + 255) / 256), dim3(256), 0, s, stats, mr, M, nt, gw);
+    hipLaunchKernelGGL(finalize_stats_kernel, dim3((M + 255) / 256), dim3(256), 0, s, stats, mr, mu, M, nt, gw);
     return hipGetLastError();
 }
 

@@ -638,7 +638,7 @@ bool gemm_ring_ok(const GemmArgs& a) {
 
 bool gemm_ln_ok(int epi, const GemmArgs& a) {
     if (!gemm_ring_ok(a)) return false;
-    if (epi == EPI_RESID_LN_F32) return gemm_ring2_ok(a) && a.out2 && a.stats && a.stats_ld == 4 * (a.N / 256);
+    if (epi == EPI_RESID_LN_F32) return gemm_ring2_ok(a) && a.out2 && a.stats && a.mu && a.stats_ld == 4 * (a.N / 256);
     return a.cs && a.mr && a.N <= 3584;      // 128 KiB ring + 2 * N * 4 + 2 KiB of LDS; mr readable for padded rows
 }
 

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
     constexpr bool RESID = (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_SCALE_RESID_F32 || RLN);
     constexpr bool F16OUT = (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_BIAS_RELU_F16);
     constexpr int E = F16OUT ? 8 : (RLN ? 28 : 16);    // epilogue store instructions per wave
-    constexpr int R = RESID ? 16 : 0;                  // residual-row prefetch loads per wave
+    constexpr int R = RESID ? (RLN ? 20 : 16) : 0;     // residual-row (+ row centre) prefetch loads per wave
     constexpr int BIAS_OFF = NST * STAGE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -222,6 +222,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
 #pragma unroll
                     for (int g2 = 0; g2 < 2; ++g2) acc[a][b][f][g2] = f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 xres[RESID ? 2 : 1][RESID ? 2 : 1][RESID ? 2 : 1][RESID ? 2 : 1];
+        float muv[RLN ? 2 : 1][RLN ? 2 : 1];          // EPI_RESID_LN: centre of this lane's rows for the fp16 copy
         for (int kt = 0; kt < nk; ++kt, ++g) {
             const int st = (g % NST) * STAGE;
             const bool xl = RESID && kt == nk - 1;
@@ -237,6 +238,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                         for (int f = 0; f < 2; ++f) {
                             int m = m0 + ha * 64 + wm * 32 + f * 16 + (lane & 15);
                             m = m < p.M ? m : p.M - 1;
+                            if constexpr (RLN) muv[ha][f] = p.mu[m];
 #pragma unroll
                             for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
@@ -319,8 +321,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                     }
             }
         } else if constexpr (RLN) {
-            // x' = x + acc + bias (fp32, in place) ; x16 = fp16(x') ; per row and per wave column group (64
-            // columns) the pair (sum, sum of squared deviations from the group mean) for the next LayerNorm
+            // x' = x + acc + bias (fp32, in place) ; x16 = fp16(x' - mu[row]) with mu = the row's previous mean (keeps
+            // the fp16 rounding relative to the row's spread, not to its offset) ; per row and per wave column group
+            // (64 columns) the pair (sum, sum of squared deviations from the group mean) for the next LayerNorm
             half_t* out2 = p.out2;
             const int sg = tn * 4 + wn;                     // column group of this wave
 #pragma unroll
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                             if (m < p.M)
                                 *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v[hb][g2];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) h16[f][hb][g2][e] = (half_t)v[hb][g2][e];
+                            for (int e = 0; e < 4; ++e) h16[f][hb][g2][e] = (half_t)(v[hb][g2][e] - muv[ha][f]);
                         }
                     sum += __shfl_xor(sum, 16, 64);
                     sum += __shfl_xor(sum, 32, 64);

@@ -37,7 +37,8 @@ struct GemmArgs {
     int M, N, K;
     int G, L;          // EPI_PATCH: patches per image, tokens per image
     const float* cs = nullptr;   // EPI_LN_*: [N] column sums of the folded weight
-    const float* mr = nullptr;   // EPI_LN_*: [M][2] (mean, rstd) per row
+    const float* mr = nullptr;   // EPI_LN_*: [M][2] (row mean minus the centre of the fp16 copy, rstd)
+    const float* mu = nullptr;   // EPI_RESID_LN: [M] centre subtracted from the fp16 copy (the row's previous mean)
     half_t* out2 = nullptr;      // EPI_RESID_LN: fp16 copy of the updated rows, leading dimension ldc
     float* stats = nullptr;      // EPI_RESID_LN: [M][stats_ld][2] partial (sum, sumsq) per row and wave column group
     int stats_ld = 0;            //   = 4 * N / 256
@@ -108,11 +109,12 @@ hipError_t launch_copy_cols(const float* x, int ld, float* out, int R, int N, hi
 // W16 [N,K], gamma/beta [K], bias [N]  ->  Wf16 = fp16(W * gamma), cs[n] = sum_k float(Wf16[n][k]), bf[n] = bias[n] + sum_k W[n][k] * beta[k]
 hipError_t launch_fold_ln(const half_t* w16, const float* gamma, const float* beta, const float* bias, half_t* wf16,
                           float* cs, float* bf, int N, int K, hipStream_t s);
-// x fp32 [M,D] -> x16 fp16 copy and mr[m] = (mean, rstd) of row m (eps 1e-5, biased variance)
-hipError_t launch_rowstats_cast(const float* x, half_t* x16, float* mr, int M, int D, hipStream_t s);
+// x fp32 [M,D] -> centred fp16 copy x16 = fp16(x - mean), mu[m] = mean, mr[m] = (0, rstd) (eps 1e-5, biased variance)
+hipError_t launch_rowstats_cast(const float* x, half_t* x16, float* mr, float* mu, int M, int D, hipStream_t s);
 // stats [M][nt][2]: per column group of gw columns (sum, sum of squared deviations from the group mean)
-// -> mr [M][2] (mean, rstd) over the nt * gw columns, eps 1e-5
-hipError_t launch_finalize_stats(const float* stats, float* mr, int M, int nt, int gw, hipStream_t s);
+// -> mr [M][2] = (mean - mu[m], rstd) over the nt * gw columns, eps 1e-5, then mu[m] = mean (the centre the next
+// residual GEMM subtracts from its fp16 copy)
+hipError_t launch_finalize_stats(const float* stats, float* mr, float* mu, int M, int nt, int gw, hipStream_t s);
 
 #define HG_PRE_HDR 24   // header words per box in the pre-processing table (layout: hg_preproc.hip)
 // ---- crop pre-processing (hg_preproc.hip): head = per-box headers written by the host, tab receives the weight

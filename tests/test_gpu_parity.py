@@ -270,6 +270,24 @@ def test_vitb16_vs_oracle_ragged_batch(fullA):
     assert out0.shape == (0, 512)
 
 
+def test_vitb16_offset_residual_stream_vs_oracle(monkeypatch):
+    """Rows of the residual stream with a large common offset (|mean| >> spread; here through ln_pre.bias and the
+    class/positional embeddings) are the hard case of the LayerNorm-folded GEMMs: the fp16 copy is stored centred on
+    the row's previous mean so that its rounding stays relative to the spread.  Both paths vs the oracle."""
+    from oracle import clip_oracle as co
+    raw = synth.clip_state_dict(synth.VIT_B16, 0)
+    raw["visual.ln_pre.bias"] = (raw["visual.ln_pre.bias"] + 6.0).astype(np.float32)
+    sd = co.reference_weight_rounding(raw)
+    img = torch.from_numpy(synth.crops(3, 224, seed=78))
+    ref = co.encode_image(sd, img).numpy()
+    m = build_model(synth.to_torch(raw)).to(dev())
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HG_LN_FUSE", mode)
+        e = check(m.visual.forward_trace(img.to(dev()))[0], ref, what=f"offset stream, HG_LN_FUSE={mode}")
+        print(f"\noffset residual stream rel-L2 vs oracle, HG_LN_FUSE={mode}: {e:.3e}")
+    monkeypatch.delenv("HG_LN_FUSE")
+
+
 def test_vae_vs_oracle_ragged_rows():
     from oracle import clip_oracle as co, vae_oracle as vo
     d = dev()
