@@ -121,7 +121,9 @@ def main():
     h = model.visual._ctx.handle
     lib = _lib.lib()
     n_layers = model.visual.transformer.layers
-    lib.hg_profile_begin(h, GEMM_CLASS_FC, args.steps * n_layers + 8)
+    # hipEvent pairs around every c_fc launch of the first (up to) 4 timed steps: an event record costs ~5 us on the
+    # stream, so timing all launches would inflate ms_per_step by ~1 %
+    lib.hg_profile_begin(h, GEMM_CLASS_FC, min(args.steps, 4) * n_layers)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
