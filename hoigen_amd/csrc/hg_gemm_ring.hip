@@ -61,13 +61,21 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     constexpr int GA = MF / 2, GB = 2;
     static_assert(GA <= 2, "DMA piece helpers cover two pieces per half-tile");
     constexpr int N1 = 2 * GA + 3 * GB, N2 = 3 * GA + 2 * GB;
-    constexpr int E = 8 * MF;                          // epilogue store instructions per wave
-    constexpr bool RESID = (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_SCALE_RESID_F32);
+    constexpr bool RLN = (EPI == EPI_RESID_LN_F32);    // residual + centred fp16 copy + LayerNorm statistics (MF = 4)
+    constexpr bool RESID = (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_SCALE_RESID_F32 || RLN);
+    // epilogue store instructions per wave (vmcnt immediates are 6 bits: anything above is clamped, i.e. stricter)
+    constexpr int E_RAW = RLN ? 8 * MF + 4 * MF + 2 * MF : 8 * MF;
+    constexpr int E = E_RAW > 52 ? 52 : E_RAW;
     // RESID at MF = 2: the residual rows are fetched one K-tile before the epilogue (64 spare VGPRs)
     constexpr bool XPRE = RESID && MF == 2;
     // folded LayerNorm (EPI_LN_*): (mean, rstd) of this lane's 2*MF rows are fetched one K-tile ahead as well
     constexpr bool LNC = (EPI == EPI_LN_BIAS_F16 || EPI == EPI_LN_BIAS_QGELU_F16);
-    constexpr int R = XPRE ? E : 0;                    // residual prefetch loads per wave in the last K-tile
+    // RESID at MF = 4: no room for all 32 residual chunks; a rolling window of ROLL_W chunks (f32x4 per lane) is
+    // filled one K-tile before the epilogue and refilled as the epilogue consumes it (the fragment registers are
+    // dead by then, the accumulators die chunk by chunk)
+    constexpr bool ROLL = RESID && MF == 4;
+    constexpr int ROLL_W = RLN ? 6 : 8;               // 8 with the LayerNorm extras spills 3 VGPRs
+    constexpr int R = XPRE ? E : (ROLL ? ROLL_W + (RLN ? 1 : 0) : 0);   // prefetch loads per wave in the last K-tile
     constexpr int BIAS_OFF = 2 * STAGE;                // bias[N] (and cs[N] for EPI_LN_*) staged in LDS behind the ring
     const int MR_OFF = BIAS_OFF + 2 * p.N * 4;         // EPI_LN_*: (mean, rstd) of the tile's BM rows, 8 B each
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -310,12 +318,25 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
         const int m0 = tm * BM, n0 = tn * 256;
         zero_acc();
         f32x4 xres[XPRE ? 2 : 1][XPRE ? 2 : 1][XPRE ? MF : 1][XPRE ? 2 : 1];
+        // rolling residual window (ROLL): chunk c = ((ha * MF + f) * 2 + hb) * 2 + g2 is this lane's f32x4 of row
+        // m0 + ha*BM/2 + wm*MF*16 + f*16 + (lane&15), columns n0 + hb*128 + wn*32 + g2*16 + 4*(lane>>4)
+        f32x4 xw[ROLL ? ROLL_W : 1];
+        float muw[RLN ? 2 : 1];
+        auto chunk_row = [&](int rg) {
+            int m = m0 + (rg / MF) * (BM / 2) + wm * MF * 16 + (rg % MF) * 16 + (lane & 15);
+            return m < p.M ? m : p.M - 1;
+        };
+        auto chunk_load = [&](int c) {
+            const int rg = c >> 2, hb = (c >> 1) & 1, g2 = c & 1;
+            const int n = n0 + hb * 128 + wn * 32 + g2 * 16 + 4 * (lane >> 4);
+            return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.out) + (size_t)chunk_row(rg) * p.ldc + n);
+        };
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         for (int kt = 0; kt < nk; ++kt, ++g) {
             const int buf = (g & 1) * STAGE;
             const bool more = g + 2 < S;          // a K-tile two positions ahead exists
             const bool post = r > 0;               // epilogue stores of the previous tile may still be pending
-            const bool xl = XPRE && kt == nk - 1;  // residual rows are fetched during the last K-tile
+            const bool xl = (XPRE || ROLL) && kt == nk - 1;  // residual rows are fetched during the last K-tile
             if constexpr (PH2) {
             // Two phases per K-tile (32 MFMAs per segment, half the barriers):
             //   PA: fetch A0 W0 W1 (t); refill A1(t+1);               wait -> A1(t) landed;        quadrants (0,0) (0,1)
@@ -331,6 +352,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                                                              (m0 + wave * (BM / 8)) * 8, 0, 0);
             }
             if (g + 1 < S) issue_A(1, 0, GA);
+            if constexpr (ROLL) {
+                if (xl) {      // first ROLL_W residual chunks (+ the first row group's centre) of this tile
+#pragma unroll
+                    for (int c = 0; c < ROLL_W; ++c) xw[c] = chunk_load(c);
+                    if constexpr (RLN) muw[0] = p.mu[chunk_row(0)];
+                }
+            }
             if constexpr (XPRE) {
                 if (xl) {
 #pragma unroll
@@ -386,6 +414,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                                                              (m0 + wave * (BM / 8)) * 8, 0, 0);
             }
             if (g + 1 < S) issue_A(1, 0, GA);     // A1 of position g+1 (ld state already at g+1)
+            if constexpr (ROLL) {
+                if (xl) {      // first ROLL_W residual chunks (+ the first row group's centre) of this tile
+#pragma unroll
+                    for (int c = 0; c < ROLL_W; ++c) xw[c] = chunk_load(c);
+                    if constexpr (RLN) muw[0] = p.mu[chunk_row(0)];
+                }
+            }
             if constexpr (XPRE) {
                 if (xl) {
 #pragma unroll
@@ -519,6 +554,82 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                                 *reinterpret_cast<u32x4*>(outp + (size_t)m * p.ldc + nb + 4 * (q & ~1)) = o;
                         }
                 }
+        } else if constexpr (ROLL) {
+            // residual epilogue through the rolling window: chunk c is consumed, stored, and its window slot is
+            // refilled with chunk c + ROLL_W (the sched_barrier keeps the compiler from hoisting the refills)
+            const int q = lane >> 4;
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int rg = 0; rg < 2 * MF; ++rg) {
+                const int ha = rg / MF, f = rg % MF;
+                const int m = m0 + ha * (BM / 2) + wm * MF * 16 + f * 16 + (lane & 15);
+                f32x4 v[2][2];
+                float mu_r = 0.f;
+                if constexpr (RLN) {
+                    mu_r = muw[rg & 1];
+                    if (rg + 1 < 2 * MF) muw[(rg + 1) & 1] = p.mu[chunk_row(rg + 1)];
+                }
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                    for (int g2 = 0; g2 < 2; ++g2) {
+                        const int c = (rg * 2 + hb) * 2 + g2;
+                        const int n = n0 + hb * 128 + wn * 32 + g2 * 16 + 4 * q;
+                        f32x4 a = acc[ha][hb][f][g2] + *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + n * 4);
+                        if constexpr (EPI == EPI_SCALE_RESID_F32) a *= *reinterpret_cast<const f32x4*>(p.pos + n);
+                        v[hb][g2] = xw[c % ROLL_W] + a;
+                        if (m < p.M)
+                            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v[hb][g2];
+                        if (c + ROLL_W < 8 * MF) xw[c % ROLL_W] = chunk_load(c + ROLL_W);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                if constexpr (RLN) {
+                    // per row and per wave column group (64 columns): (sum, sum of squared deviations from the group
+                    // mean); fp16 copy centred on the row's previous mean
+                    float sum = 0.f;
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                        for (int g2 = 0; g2 < 2; ++g2) sum += (v[hb][g2][0] + v[hb][g2][1]) + (v[hb][g2][2] + v[hb][g2][3]);
+                    sum += __shfl_xor(sum, 16, 64);
+                    sum += __shfl_xor(sum, 32, 64);
+                    const float gm = sum * (1.0f / 64.0f);
+                    float m2 = 0.f;
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                        for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float d = v[hb][g2][e] - gm;
+                                m2 = fmaf(d, d, m2);
+                            }
+                    m2 += __shfl_xor(m2, 16, 64);
+                    m2 += __shfl_xor(m2, 32, 64);
+                    if (q == 0 && m < p.M) {
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        *reinterpret_cast<f32x2*>(p.stats + ((size_t)m * p.stats_ld + (n0 / 256) * 4 + wn) * 2) = f32x2{sum, m2};
+                    }
+                    // fp16 copy: the column blocks g2 = 0, 1 of this row are paired through v_permlane16_swap
+                    // (even 16-lane groups end up with 8 consecutive columns of block 0, odd groups of block 1)
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb) {
+                        half4 h0, h1;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            h0[e] = (half_t)(v[hb][0][e] - mu_r);
+                            h1[e] = (half_t)(v[hb][1][e] - mu_r);
+                        }
+                        const u32x2 ux = __builtin_bit_cast(u32x2, h0), uy = __builtin_bit_cast(u32x2, h1);
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(ux[0], uy[0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(ux[1], uy[1], false, false);
+                        const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                        const int nc = n0 + hb * 128 + wn * 32 + ((q & 1) ? 16 : 0) + 4 * (q & ~1);
+                        if (m < p.M) *reinterpret_cast<u32x4*>(p.out2 + (size_t)m * p.ldc + nc) = o;
+                    }
+                }
+            }
         } else {
 #pragma unroll
         for (int ha = 0; ha < 2; ++ha)
@@ -643,13 +754,23 @@ bool gemm_ln_ok(int epi, const GemmArgs& a) {
 }
 
 hipError_t launch_gemm_ring(int epi, const GemmArgs& a, hipStream_t s) {
-    if (epi == EPI_RESID_LN_F32) return launch_gemm_ring2(epi, a, s);
     const bool lnc = (epi == EPI_LN_BIAS_F16 || epi == EPI_LN_BIAS_QGELU_F16);
-    // 256x256 tiles when they fill the chip evenly enough, else 128x256 (N = 768 GEMMs: 591 vs 1182 tiles)
-    const int t256 = ((a.M + 255) / 256) * (a.N / 256);
-    const int rounds = (t256 + 255) / 256;
+    const bool resid = (epi == EPI_BIAS_RESID_F32 || epi == EPI_SCALE_RESID_F32 || epi == EPI_RESID_LN_F32);
+    // 256x256 tiles when they fill the chip evenly enough, else 128x256 (N = 768 GEMMs: 591 vs 1182 tiles).
+    // The 128x256 kernel needs 50 % more global->LDS traffic per FLOP and runs at ~0.8 of a 256x256 tile's time
+    // per (half-size) tile, so with the residual epilogues (rolling window at 256 rows) the big tile wins as soon
+    // as rounds(256) <= 0.8 * rounds(128): N = 768, M = 50432: 3 vs 5 * 0.8.
+    const int t256 = ((a.M + 255) / 256) * (a.N / 256), t128 = ((a.M + 127) / 128) * (a.N / 256);
+    const int rounds = (t256 + 255) / 256, rounds128 = (t128 + 255) / 256;
     static const int force_big = []() { const char* e = getenv("HG_RING_BIG"); return e ? atoi(e) : 0; }();
-    const bool big = force_big == 1 ? true : (force_big == 2 || force_big == 3) ? false : (t256 >= 256 && (double)t256 / (rounds * 256.0) >= 0.9);
+    bool big = t256 >= 256 && (double)t256 / (rounds * 256.0) >= 0.9;
+    // ... measured at N = 768, M = 50432: plain residual 272 vs 298 us (K = 3072).  With the LayerNorm extras
+    // (fp16 copy + statistics: 387 MB per launch) the epilogue is an HBM burst of every CU at once, and three big
+    // bursts overlap worse than five small ones (K = 768: 154 vs 127 us; K = 3072: 300 vs 303): keep 128 rows.
+    if (resid && epi != EPI_RESID_LN_F32 && t256 >= 256 && (double)rounds <= 0.8 * rounds128 + 1e-9) big = true;
+    if (force_big == 1) big = true;
+    if (force_big == 2 || force_big == 3) big = false;
+    if (epi == EPI_RESID_LN_F32 && !big) return launch_gemm_ring2(epi, a, s);     // no 128-row variant in this kernel
     if (!big && force_big != 3 && !lnc && gemm_ring2_ok(a)) return launch_gemm_ring2(epi, a, s);   // 128x256, two-phase
     // 256x256 tiles run two phases per K-tile (32 MFMAs per segment): -4..8 % vs four phases; HG_RING_PH2=0 = four
     static const bool ph2 = []() { const char* e = getenv("HG_RING_PH2"); return e ? atoi(e) != 0 : true; }();
@@ -667,6 +788,8 @@ hipError_t launch_gemm_ring(int epi, const GemmArgs& a, hipStream_t s) {
         HG_RING(EPI_SCALE_RESID_F32);
         HG_RING(EPI_LN_BIAS_F16);
         HG_RING(EPI_LN_BIAS_QGELU_F16);
+        case EPI_RESID_LN_F32:
+            return ph2 ? launch_ring_t<4, EPI_RESID_LN_F32, true>(a, s) : launch_ring_t<4, EPI_RESID_LN_F32, false>(a, s);
         default: return hipErrorInvalidValue;
     }
 #undef HG_RING

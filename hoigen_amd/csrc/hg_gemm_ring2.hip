@@ -17,6 +17,7 @@
 // Stage t%3 is refilled with tile t+3: its W halves as soon as PA(t) has read them (issued in PB(t)), its A
 // once PB(t) has read half 1 (issued in PA(t+1)).  Two K-tiles (96 KiB) are in flight across the barriers.
 // Every phase is [fetch] barrier [16 MFMAs] barrier, waves 4-7 one barrier interval behind waves 0-3.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -24,6 +25,19 @@
 #include "hg_gemm_dev.h"
 
 namespace hg {
+
+// Diagnostic build (-DHG_STAMPS -DHG_STAMP_MASK=bits): per-wave s_memtime totals, as in hg_gemm_ring.hip
+// (0 vmcnt waits, 1 lgkmcnt waits, 2 fetch barriers, 3 MFMA segments, 4 MFMA barriers, 7 epilogue)
+#ifdef HG_STAMPS
+#ifndef HG_STAMP_MASK
+#define HG_STAMP_MASK 0xFF
+#endif
+#define SEG_B(k) do { if constexpr ((HG_STAMP_MASK >> (k)) & 1) t_beg = __builtin_amdgcn_s_memtime(); } while (0)
+#define SEG_E(k) do { if constexpr ((HG_STAMP_MASK >> (k)) & 1) tacc[k] += __builtin_amdgcn_s_memtime() - t_beg; } while (0)
+#else
+#define SEG_B(k) do {} while (0)
+#define SEG_E(k) do {} while (0)
+#endif
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int tiles_n, const int n_tiles,
@@ -42,6 +56,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
     constexpr int R = RESID ? (RLN ? 20 : 16) : 0;     // residual-row (+ row centre) prefetch loads per wave
     constexpr int BIAS_OFF = NST * STAGE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef HG_STAMPS
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_beg = 0, t_all = 0;
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -165,6 +182,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
     f32x4 acc[2][2][2][2];
     auto mma = [&](auto HA) {
         constexpr int ha = decltype(HA)::value;
+        SEG_B(3);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -177,17 +195,24 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                         acc[ha][hb][f][g2] =
                             __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[hb][g2][ks], xa[f][ks], acc[ha][hb][f][g2], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
+        SEG_E(3);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     auto sync_fetch = [&]() {
+        SEG_B(1);
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0); the builtin keeps the compiler's waitcnt scoreboard in sync
+        SEG_E(1);
+        SEG_B(2);
         barrier_raw();
+        SEG_E(2);
         __builtin_amdgcn_sched_barrier(0);
     };
     auto sync_mma = [&]() {
         __builtin_amdgcn_sched_barrier(0);
+        SEG_B(4);
         barrier_raw();
+        SEG_E(4);
     };
 
     // ---- bias -> LDS once per workgroup
@@ -208,6 +233,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
     const bool late = (wave >= 4) && !(mode & 8);
     if (late) barrier_raw();
 
+#ifdef HG_STAMPS
+    t_all = __builtin_amdgcn_s_memtime();
+#endif
     int g = 0;
     for (int r = 0; r < my_tiles; ++r) {
         int tm, tn;
@@ -264,17 +292,20 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
             read_A(1, st);
             const bool issued = g + 3 < S;
             if (issued) issue_W();
+            SEG_B(0);
             if (g + 1 < S) {
                 if (!issued) wait_vm<0>();
                 else if (xl) wait_vm<NWT + R>();
                 else if (r > 0 && kt == 0) wait_vm<NWT + E>();
                 else wait_vm<NWT>();
             }
+            SEG_E(0);
             sync_fetch();
             mma(I1{});
             sync_mma();
         }
         // ---------------- epilogue
+        SEG_B(7);
         if (mode & 4) {
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -415,7 +446,17 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                         }
                 }
         }
+        SEG_E(7);
     }
+#ifdef HG_STAMPS
+    if (p.dbg && lane == 0) {
+        unsigned long long* d = p.dbg + (size_t)(blockIdx.x * 8 + wave) * 16;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = tacc[k];
+        d[8] = __builtin_amdgcn_s_memtime() - t_all;
+        d[9] = (unsigned long long)my_tiles * nk;
+    }
+#endif
     if (!late) barrier_raw();   // balances the extra barrier of the late waves
 #endif
 }
@@ -454,6 +495,34 @@ static hipError_t launch_ring2_t(const GemmArgs& a, hipStream_t s) {
     int gsz = gsz_env > 0 ? gsz_env : (int)((1536 * 1024) / ((size_t)512 * a.K));
     if (gsz < 3) gsz = 3;
     if (gsz > tiles_n) gsz = tiles_n;
+#ifdef HG_STAMPS
+    if (getenv("HG_STAMPS")) {
+        const size_t n = (size_t)grid * 8 * 16;
+        unsigned long long* d = nullptr;
+        if (hipMalloc(&d, n * 8) != hipSuccess) return hipErrorOutOfMemory;
+        hipMemsetAsync(d, 0, n * 8, s);
+        GemmArgs b = a;
+        b.dbg = d;
+        hipLaunchKernelGGL((gemm_ring2<EPI>), dim3(grid), dim3(512), LDS, s, b, tiles_n, n_tiles, (unsigned)a_bytes, mode, gsz);
+        hipStreamSynchronize(s);
+        unsigned long long* h = (unsigned long long*)malloc(n * 8);
+        hipMemcpy(h, d, n * 8, hipMemcpyDeviceToHost);
+        static const char* names[8] = {"vmcnt", "lgkmcnt", "fetch-barrier", "MFMA", "mfma-barrier", "-", "-", "epilogue"};
+        for (int w = 0; w < 8; w += 4) {
+            double acc[10] = {0};
+            for (int blk = 0; blk < grid; ++blk)
+                for (int k = 0; k < 10; ++k) acc[k] += (double)h[(size_t)(blk * 8 + w) * 16 + k];
+            const double kts = acc[9] > 0 ? acc[9] : 1;
+            fprintf(stderr, "[stamps] ring2<%d> N=%d K=%d wave %d: loop %.0f cycles/K-tile;", EPI, a.N, a.K, w, acc[8] / kts);
+            for (int k = 0; k < 8; ++k)
+                if (((HG_STAMP_MASK >> k) & 1) && names[k][0] != '-') fprintf(stderr, " %s %.0f", names[k], acc[k] / kts);
+            fprintf(stderr, "\n");
+        }
+        free(h);
+        hipFree(d);
+        return hipGetLastError();
+    }
+#endif
     hipLaunchKernelGGL((gemm_ring2<EPI>), dim3(grid), dim3(512), LDS, s, a, tiles_n, n_tiles, (unsigned)a_bytes, mode, gsz);
     return hipGetLastError();
 }
