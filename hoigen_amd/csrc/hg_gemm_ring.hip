@@ -55,6 +55,13 @@ template <int MF, int EPI, bool PH2>
 __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int tiles_n, const int n_tiles,
                                                     const unsigned a_bytes, const int mode, const int gsz) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins (buffer resources, LDS DMA): host sees just the stub
+    // timing-experiment switches (HG_RING_MODE bits 1 locality, 2 no MFMA, 4 no epilogue, 8 no stagger, 16 coalesced
+    // stores) exist only in a -DHG_EXPERIMENTS build: run-time branches in the K loop cost several per cent
+#ifdef HG_EXPERIMENTS
+    const int xmode = mode;
+#else
+    constexpr int xmode = 0;
+#endif
     constexpr int BM = 64 * MF, BK = 64;
     constexpr int AH = MF * 4096, BH = 16384;          // bytes per A / W half-tile slot
     constexpr int STAGE = 2 * AH + 2 * BH;
@@ -163,8 +170,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             ++ld_r;
             int tm, tn;
             tile_of(slot + ld_r * cpx, tm, tn);
-            ld_sA = (mode & 1) ? 0 : tm * BM * p.lda * 2;     // mode 1 (timing experiment): every tile reads tile 0
-            ld_sW = (mode & 1) ? 0 : tn * 256 * p.K * 2;
+            ld_sA = (xmode & 1) ? 0 : tm * BM * p.lda * 2;     // mode 1 (timing experiment): every tile reads tile 0
+            ld_sW = (xmode & 1) ? 0 : tn * 256 * p.K * 2;
         }
         ld_buf = (ld_g & 1) * STAGE;
     };
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     };
     auto mma = [&](auto HA, auto HB) {
         constexpr int ha = decltype(HA)::value, hb = decltype(HB)::value;
-        if (mode & 2) {   // timing experiment: no MFMAs (operands kept live)
+        if (xmode & 2) {   // timing experiment: no MFMAs (operands kept live)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     barrier_raw();
     // Stagger: waves 4-7 (the second wave of every SIMD) run one barrier interval behind waves 0-3, so a
     // SIMD always has one wave in a fetch segment (LDS reads, DMA issue, waits) and one in an MFMA segment.
-    const bool late = (wave >= 4) && !(mode & 8);
+    const bool late = (wave >= 4) && !(xmode & 8);
     if (late) barrier_raw();
 
 #ifdef HG_STAMPS
@@ -482,7 +489,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
         }
         // ---------------- epilogue of tile r (the ring keeps prefetching the next tile meanwhile)
         SEG_B(7);
-        if (mode & 4) {   // timing experiment: no epilogue
+        if (xmode & 4) {   // timing experiment: no epilogue
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -545,7 +552,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                             const auto s1 = __builtin_amdgcn_permlane16_swap(ux[1], uy[1], false, false);
                             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                             const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
-                            if (mode & 16) {   // timing experiment: lane-linear (fully coalesced, WRONG) addresses
+                            if (xmode & 16) {   // timing experiment: lane-linear (fully coalesced, WRONG) addresses
                                 const int idx = ((ha * (MF / 2) + f / 2) * 2 + hb) * 2 + g2;
                                 const int rr = m0 + (wave * (4 * MF) + idx) * 2 + (lane >> 5);
                                 if (rr < p.M) *reinterpret_cast<u32x4*>(outp + (size_t)rr * p.ldc + n0 + (lane & 31) * 8) = o;

@@ -43,6 +43,13 @@ template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int tiles_n, const int n_tiles,
                                                      const unsigned a_bytes, const int mode, const int gsz) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins (buffer resources, LDS DMA): host sees just the stub
+    // timing-experiment switches (HG_RING_MODE bits 1 locality, 2 no MFMA, 4 no epilogue, 8 no stagger, 16 coalesced
+    // stores) exist only in a -DHG_EXPERIMENTS build: run-time branches in the K loop cost several per cent
+#ifdef HG_EXPERIMENTS
+    const int xmode = mode;
+#else
+    constexpr int xmode = 0;
+#endif
     constexpr int BM = 128, BK = 64;
     constexpr int AB = 16384, WH = 16384;              // bytes: A tile (both halves), one W half
     constexpr int STAGE = AB + 2 * WH;                 // 48 KiB
@@ -230,7 +237,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
     else if (S > 1) wait_vm<GW + GA>();
     else wait_vm<0>();
     barrier_raw();
-    const bool late = (wave >= 4) && !(mode & 8);
+    const bool late = (wave >= 4) && !(xmode & 8);
     if (late) barrier_raw();
 
 #ifdef HG_STAMPS
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
 #pragma unroll
                                 for (int g2 = 0; g2 < 2; ++g2) {
                                     const int n = n0 + hb * 128 + wn * 32 + g2 * 16 + 4 * (lane >> 4);
-                                    if (mode & 16) {
+                                    if (xmode & 16) {
                                         const int idx = ((ha * 2 + f) * 2 + hb) * 2 + g2;
                                         int rr = m0 + wave * 16 + idx;
                                         rr = rr < p.M ? rr : p.M - 1;
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
         }
         // ---------------- epilogue
         SEG_B(7);
-        if (mode & 4) {
+        if (xmode & 4) {
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -428,7 +435,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                             const int n = n0 + hb * 128 + wn * 32 + g2 * 16 + 4 * q;
                             f32x4 v = acc[ha][hb][f][g2] + *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + n * 4);
                             if constexpr (RESID) {
-                                if (mode & 16) {
+                                if (xmode & 16) {
                                     const int idx = ((ha * 2 + f) * 2 + hb) * 2 + g2;
                                     const int rr = m0 + wave * 16 + idx;
                                     if (rr < p.M)

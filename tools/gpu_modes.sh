@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B sweep of one environment knob inside ONE gpurun call (boxes differ by +-10 %):
-#   VAR=HG_RING_MODE VALS="0 16 4" bash tools/gpu_modes.sh
+#   VAR=HG_RING_GSZ VALS="0 3 6" bash tools/gpu_modes.sh
+# (HG_RING_MODE experiment bits need a build with HG_EXTRA_FLAGS=-DHG_EXPERIMENTS)
 R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
 VAR=${VAR:-HG_RING_MODE}
 for g in ${VALS:-0 4 0}; do
