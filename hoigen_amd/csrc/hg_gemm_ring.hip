@@ -339,12 +339,16 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.out) + (size_t)chunk_row(rg) * p.ldc + n);
         };
         typedef float f32x2 __attribute__((ext_vector_type(2)));
-        for (int kt = 0; kt < nk; ++kt, ++g) {
+        // One K-tile of the two-phase schedule.  KIND: 0 middle, 1 first of a tile (the previous epilogue's stores may be
+        // pending), 2 second to last (LayerNorm statistics DMA), 3 last (residual prefetch).  K >= 256 makes the four
+        // kinds distinct K-tiles, and every K-tile before the last two of a tile has two successors in the stream, so
+        // the middle of the loop carries no run-time conditions at all.
+        auto ph2_ktile = [&](auto KIND_T) {
+            constexpr int KIND = decltype(KIND_T)::value;
             const int buf = (g & 1) * STAGE;
-            const bool more = g + 2 < S;          // a K-tile two positions ahead exists
-            const bool post = r > 0;               // epilogue stores of the previous tile may still be pending
-            const bool xl = (XPRE || ROLL) && kt == nk - 1;  // residual rows are fetched during the last K-tile
-            if constexpr (PH2) {
+            const bool post = r > 0;
+            const bool more = KIND < 2 || r + 1 < my_tiles;      // a K-tile two positions ahead exists
+            (void)post; (void)more;
             // Two phases per K-tile (32 MFMAs per segment, half the barriers):
             //   PA: fetch A0 W0 W1 (t); refill A1(t+1);               wait -> A1(t) landed;        quadrants (0,0) (0,1)
             //   PB: fetch A1 (t);       refill A0 W0 W1 (t+2);         wait -> A0 W0 W1 (t+1) landed; quadrants (1,1) (1,0)
@@ -353,21 +357,21 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             read_A(0, buf);
             read_W(I0{}, buf);
             read_W(I1{}, buf);
-            if constexpr (LNC) {
-                if (kt == nk - 2 && lane < BM / 16)
+            if constexpr (LNC && KIND == 2) {
+                if (lane < BM / 16)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsM, (HG_LDS void*)(smem + MR_OFF + wave * BM), 16, lane * 16,
                                                              (m0 + wave * (BM / 8)) * 8, 0, 0);
             }
-            if (g + 1 < S) issue_A(1, 0, GA);
-            if constexpr (ROLL) {
-                if (xl) {      // first ROLL_W residual chunks (+ the first row group's centre) of this tile
+            if (KIND < 3 || more) issue_A(1, 0, GA);      // A1 of position g+1 exists unless the stream ends here
+            if constexpr (ROLL && KIND == 3) {
+                {      // first ROLL_W residual chunks (+ the first row group's centre) of this tile
 #pragma unroll
                     for (int c = 0; c < ROLL_W; ++c) xw[c] = chunk_load(c);
                     if constexpr (RLN) muw[0] = p.mu[chunk_row(0)];
                 }
             }
-            if constexpr (XPRE) {
-                if (xl) {
+            if constexpr (XPRE && KIND == 3) {
+                {
 #pragma unroll
                     for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
@@ -386,28 +390,44 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                 }
             }
             SEG_B(0);
-            if (!more) wait_vm<0>();
-            else if (xl) wait_vm<NP + R>();
-            else if (post && kt == 0) wait_vm<NP + E>();
-            else wait_vm<NP>();
+            if constexpr (KIND == 0) wait_vm<NP>();
+            else if constexpr (KIND == 1) { if (post) wait_vm<NP + E>(); else wait_vm<NP>(); }
+            else if constexpr (KIND == 2) { if (more) wait_vm<NP>(); else wait_vm<0>(); }
+            else { if (more) wait_vm<NP + R>(); else wait_vm<0>(); }
             SEG_E(0);
             sync_fetch();
             mma(I0{}, I0{});
             mma(I0{}, I1{});
             sync_mma();
             read_A(1, buf);
-            if (more) { ld_advance(); issue_A(0, 0, GA); issue_W(0, 0, GB); issue_W(1, 0, GB); }
+            if (KIND < 2 || more) { ld_advance(); issue_A(0, 0, GA); issue_W(0, 0, GB); issue_W(1, 0, GB); }
             SEG_B(0);
-            if (!more) wait_vm<0>();
-            else if (xl) wait_vm<NP + R>();
-            else if (post && kt == 0) wait_vm<NP + E>();
-            else wait_vm<NP>();
+            if constexpr (KIND == 0) wait_vm<NP>();
+            else if constexpr (KIND == 1) { if (post) wait_vm<NP + E>(); else wait_vm<NP>(); }
+            else if constexpr (KIND == 2) { if (more) wait_vm<NP>(); else wait_vm<0>(); }
+            else { if (more) wait_vm<NP + R>(); else wait_vm<0>(); }
             SEG_E(0);
             sync_fetch();
             mma(I1{}, I1{});
             mma(I1{}, I0{});
             sync_mma();
-            } else {
+            ++g;
+        };
+        if constexpr (PH2) {
+            using K0 = std::integral_constant<int, 0>;
+            using K1 = std::integral_constant<int, 1>;
+            using K2 = std::integral_constant<int, 2>;
+            using K3 = std::integral_constant<int, 3>;
+            ph2_ktile(K1{});
+            for (int kt = 1; kt < nk - 2; ++kt) ph2_ktile(K0{});
+            ph2_ktile(K2{});
+            ph2_ktile(K3{});
+        } else {
+        for (int kt = 0; kt < nk; ++kt, ++g) {
+            const int buf = (g & 1) * STAGE;
+            const bool more = g + 2 < S;          // a K-tile two positions ahead exists
+            const bool post = r > 0;               // epilogue stores of the previous tile may still be pending
+            const bool xl = (XPRE || ROLL) && kt == nk - 1;  // residual rows are fetched during the last K-tile
             // ---------------- P1: fetch A0(t), W0(t); refill A1(t+1); then quadrant (0,0)
             read_A(0, buf);
             read_W(I0{}, buf);
@@ -485,7 +505,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             sync_fetch();
             mma(I1{}, I0{});
             sync_mma();
-                    }
+                            }
         }
         // ---------------- epilogue of tile r (the ring keeps prefetching the next tile meanwhile)
         SEG_B(7);
