@@ -243,7 +243,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
 #ifdef HG_STAMPS
     t_all = __builtin_amdgcn_s_memtime();
 #endif
-    int g = 0;
+    int g = 0, stg = 0;                        // K-tile position in the stream and its LDS stage (g % NST)
     for (int r = 0; r < my_tiles; ++r) {
         int tm, tn;
         tile_of(slot + r * cpx, tm, tn);
@@ -258,15 +258,21 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                     for (int g2 = 0; g2 < 2; ++g2) acc[a][b][f][g2] = f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 xres[RESID ? 2 : 1][RESID ? 2 : 1][RESID ? 2 : 1][RESID ? 2 : 1];
         float muv[RLN ? 2 : 1][RLN ? 2 : 1];          // EPI_RESID_LN: centre of this lane's rows for the fp16 copy
-        for (int kt = 0; kt < nk; ++kt, ++g) {
-            const int st = (g % NST) * STAGE;
-            const bool xl = RESID && kt == nk - 1;
+        // One K-tile.  KIND: 0 middle, 1 first of a tile (the previous epilogue's stores may be pending), 2 / 3 / 4 the
+        // third-to-last, second-to-last and last K-tile of a tile: only there the refills (A at distance 2, W at
+        // distance 3) and the waits depend on whether another tile follows.  K >= 256 keeps the kinds distinct.
+        auto ktile = [&](auto KIND_T) {
+            constexpr int KIND = decltype(KIND_T)::value;
+            const int st = stg * STAGE;
+            stg = stg == NST - 1 ? 0 : stg + 1;
+            const bool more = KIND < 2 || r + 1 < my_tiles;
+            (void)more;
             // ---------------- PA: fetch A0, W0, W1 of this K-tile; refill A(g+2); quadrants (A0,W0) (A0,W1)
             read_A(0, st);
             read_W(st);
-            if (g + 2 < S) issue_A();
-            if constexpr (RESID) {
-                if (xl) {      // residual rows of this tile, needed by the epilogue one K-tile later
+            if (KIND < 3 || more) issue_A();              // K-tile g+2 exists
+            if constexpr (RESID && KIND == 4) {
+                {      // residual rows of this tile, needed by the epilogue one K-tile later
 #pragma unroll
                     for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
@@ -297,19 +303,29 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
             sync_mma();
             // ---------------- PB: fetch A1; refill W(g+3); wait for A,W(g+1); quadrants (A1,W0) (A1,W1)
             read_A(1, st);
-            const bool issued = g + 3 < S;
-            if (issued) issue_W();
+            if (KIND < 2 || more) issue_W();              // K-tile g+3 exists
             SEG_B(0);
-            if (g + 1 < S) {
-                if (!issued) wait_vm<0>();
-                else if (xl) wait_vm<NWT + R>();
-                else if (r > 0 && kt == 0) wait_vm<NWT + E>();
-                else wait_vm<NWT>();
-            }
+            if constexpr (KIND == 0) wait_vm<NWT>();
+            else if constexpr (KIND == 1) { if (r > 0) wait_vm<NWT + E>(); else wait_vm<NWT>(); }
+            else if constexpr (KIND == 4) { if (more) wait_vm<NWT + R>(); }       // no successor: nothing to wait for
+            else { if (more) wait_vm<NWT>(); else wait_vm<0>(); }
             SEG_E(0);
             sync_fetch();
             mma(I1{});
             sync_mma();
+                    ++g;
+        };
+        {
+            using K0 = std::integral_constant<int, 0>;
+            using K1 = std::integral_constant<int, 1>;
+            using K2 = std::integral_constant<int, 2>;
+            using K3 = std::integral_constant<int, 3>;
+            using K4 = std::integral_constant<int, 4>;
+            ktile(K1{});
+            for (int kt = 1; kt < nk - 3; ++kt) ktile(K0{});
+            ktile(K2{});
+            ktile(K3{});
+            ktile(K4{});
         }
         // ---------------- epilogue
         SEG_B(7);
