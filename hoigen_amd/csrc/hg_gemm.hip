@@ -24,7 +24,9 @@ static constexpr int GEMM_LDS = 2 * STAGE_BYTES;         // double buffered: 64 
 
 __device__ __forceinline__ float quick_gelu(float v) {
     // x * sigmoid(1.702 x)
-    return v * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v));
+    float r = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -2.4554669595930157f));   // as hg_gemm_dev.h
+    asm volatile("" : "+v"(r));
+    return r;
 }
 
 template <int EPI>

@@ -4,7 +4,17 @@
 
 namespace hg {
 
-__device__ __forceinline__ float quick_gelu_r(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v)); }
+// x * sigmoid(1.702 x) = x / (1 + 2^(-1.702 log2(e) x)): one constant multiply and the hardware exp2 / rcp, written
+// out so that every kernel (and every code layout) rounds identically (a row's result must not depend on which
+// kernel its batch size selects) - __expf leaves the compiler free to merge or
+// not merge its log2(e) multiply with ours
+__device__ __forceinline__ float quick_gelu_r(float v) {
+    float r = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -2.4554669595930157f));
+    // keep the product a rounded fp32 value: otherwise the compiler fuses this multiply with the fp16 conversion
+    // (v_fma_mixlo_f16, one rounding) for some elements and not for others, differently in every kernel
+    asm volatile("" : "+v"(r));
+    return r;
+}
 
 template <int EPI>
 __device__ __forceinline__ void epilogue_ring(const GemmArgs& p, int m, int n, f32x4 v) {

@@ -526,6 +526,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             // accumulator tiles f, f+1 (same columns, rows 16 apart) so that even 16-lane groups end up with 8
             // consecutive columns of tile f's row and odd groups with 8 of tile f+1's row: 16-byte stores,
             // half the store instructions (the tail is store-issue bound).
+            // tiles that lie entirely inside M (all of them at M = 197 * 256) skip the per-store row masks
+            auto f16_epilogue = [&](auto INTERIOR_T) {
+            constexpr bool INTERIOR = decltype(INTERIOR_T)::value;
             const int q = lane >> 4;
             half_t* outp = reinterpret_cast<half_t*>(p.out);
 #pragma unroll
@@ -577,10 +580,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                                 const int rr = m0 + (wave * (4 * MF) + idx) * 2 + (lane >> 5);
                                 if (rr < p.M) *reinterpret_cast<u32x4*>(outp + (size_t)rr * p.ldc + n0 + (lane & 31) * 8) = o;
                             } else
-                            if (m < p.M)
+                            if (INTERIOR || m < p.M)
                                 *reinterpret_cast<u32x4*>(outp + (size_t)m * p.ldc + nb + 4 * (q & ~1)) = o;
                         }
                 }
+            };
+            if (m0 + BM <= p.M) f16_epilogue(std::true_type{});
+            else f16_epilogue(std::false_type{});
         } else if constexpr (ROLL) {
             // residual epilogue through the rolling window: chunk c is consumed, stored, and its window slot is
             // refilled with chunk c + ROLL_W (the sched_barrier keeps the compiler from hoisting the refills)

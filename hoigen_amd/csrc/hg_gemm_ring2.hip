@@ -341,6 +341,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
             continue;
         }
         const int q = lane >> 4;
+        // tiles entirely inside M (all of them at M = 197 * 256) skip the per-store row masks
+        auto epilogue = [&](auto INTERIOR_T) {
+        constexpr bool INTERIOR = decltype(INTERIOR_T)::value;
         if constexpr (F16OUT) {
             half_t* outp = reinterpret_cast<half_t*>(p.out);
 #pragma unroll
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                         const auto s0 = __builtin_amdgcn_permlane16_swap(ux[0], uy[0], false, false);
                         const auto s1 = __builtin_amdgcn_permlane16_swap(ux[1], uy[1], false, false);
                         const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
-                        if (m < p.M) *reinterpret_cast<u32x4*>(outp + (size_t)m * p.ldc + nb + 4 * (q & ~1)) = o;
+                        if (INTERIOR || m < p.M) *reinterpret_cast<u32x4*>(outp + (size_t)m * p.ldc + nb + 4 * (q & ~1)) = o;
                     }
             }
         } else if constexpr (RLN) {
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                             v[hb][g2] = xres[ha][hb][f][g2] +
                                         (acc[ha][hb][f][g2] + *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + n * 4));
                             sum += (v[hb][g2][0] + v[hb][g2][1]) + (v[hb][g2][2] + v[hb][g2][3]);
-                            if (m < p.M)
+                            if (INTERIOR || m < p.M)
                                 *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v[hb][g2];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) h16[f][hb][g2][e] = (half_t)(v[hb][g2][e] - muv[ha][f]);
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                             }
                     m2 += __shfl_xor(m2, 16, 64);
                     m2 += __shfl_xor(m2, 32, 64);
-                    if (q == 0 && m < p.M) {
+                    if (q == 0 && (INTERIOR || m < p.M)) {
                         typedef float f32x2 __attribute__((ext_vector_type(2)));
                         *reinterpret_cast<f32x2*>(p.stats + ((size_t)m * p.stats_ld + sg) * 2) = f32x2{sum, m2};
                     }
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                         const auto s0 = __builtin_amdgcn_permlane16_swap(ux[0], uy[0], false, false);
                         const auto s1 = __builtin_amdgcn_permlane16_swap(ux[1], uy[1], false, false);
                         const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
-                        if (m < p.M) *reinterpret_cast<u32x4*>(out2 + (size_t)m * p.ldc + nb + 4 * (q & ~1)) = o;
+                        if (INTERIOR || m < p.M) *reinterpret_cast<u32x4*>(out2 + (size_t)m * p.ldc + nb + 4 * (q & ~1)) = o;
                     }
             }
         } else {
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                                         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)rr * p.ldc + n0 + lane * 4) =
                                             xres[ha][hb][f][g2] + v;
                                 } else
-                                if (m < p.M) {
+                                if (INTERIOR || m < p.M) {
                                     if constexpr (EPI == EPI_SCALE_RESID_F32) v *= *reinterpret_cast<const f32x4*>(p.pos + n);
                                     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) =
                                         xres[ha][hb][f][g2] + v;
@@ -469,6 +472,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                         }
                 }
         }
+        };
+        if (m0 + BM <= p.M) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
         SEG_E(7);
     }
 #ifdef HG_STAMPS
