@@ -45,6 +45,19 @@ __device__ __forceinline__ void epilogue_ring(const GemmArgs& p, int m, int n, f
     }
 }
 
+// x + x(lane ^ 16) + x(lane ^ 32) + x(lane ^ 48): the sum over the four 16-lane rows, in every lane, with two
+// v_permlane*_swap instead of four ds_bpermute round trips.  v_permlane16_swap exchanges the odd rows of its first
+// operand with the even rows of the second, v_permlane32_swap the upper half of the first with the lower half of
+// the second; called with the same value twice, first + second is the pairwise sum.
+__device__ __forceinline__ float sum_rows(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float y = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
+    const unsigned v = __builtin_bit_cast(unsigned, y);
+    const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

@@ -625,8 +625,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                     for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
                         for (int g2 = 0; g2 < 2; ++g2) sum += (v[hb][g2][0] + v[hb][g2][1]) + (v[hb][g2][2] + v[hb][g2][3]);
-                    sum += __shfl_xor(sum, 16, 64);
-                    sum += __shfl_xor(sum, 32, 64);
+                    sum = sum_rows(sum);
                     const float gm = sum * (1.0f / 64.0f);
                     float m2 = 0.f;
 #pragma unroll
@@ -638,8 +637,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                                 const float d = v[hb][g2][e] - gm;
                                 m2 = fmaf(d, d, m2);
                             }
-                    m2 += __shfl_xor(m2, 16, 64);
-                    m2 += __shfl_xor(m2, 32, 64);
+                    m2 = sum_rows(m2);
                     if (q == 0 && m < p.M) {
                         typedef float f32x2 __attribute__((ext_vector_type(2)));
                         *reinterpret_cast<f32x2*>(p.stats + ((size_t)m * p.stats_ld + (n0 / 256) * 4 + wn) * 2) = f32x2{sum, m2};

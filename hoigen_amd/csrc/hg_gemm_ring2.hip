@@ -133,10 +133,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
         voffW[i] = row * p.K * 2 + c * 16;
     }
     // ---- two load streams (A and W are issued in different phases)
-    struct Ld { int g, kt, r, soff, st; };
-    Ld lA{-1, nk - 1, -1, 0, 0}, lW{-1, nk - 1, -1, 0, 0};
+    struct Ld { int kt, r, soff, st; };          // K-tile inside its tile, tile, tile origin (bytes), LDS stage offset
+    Ld lA{nk - 1, -1, 0, (NST - 1) * STAGE}, lW{nk - 1, -1, 0, (NST - 1) * STAGE};
     auto advance = [&](Ld& l, bool isA) {
-        ++l.g;
         if (++l.kt == nk) {
             l.kt = 0;
             ++l.r;
@@ -144,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
             tile_of(slot + l.r * cpx, tm, tn);
             l.soff = isA ? tm * BM * p.lda * 2 : tn * 256 * p.K * 2;
         }
-        l.st = (l.g % NST) * STAGE;
+        l.st = l.st == (NST - 1) * STAGE ? 0 : l.st + STAGE;      // stage of stream position g is g % NST
     };
     auto issue_A = [&]() {
         advance(lA, true);
@@ -404,8 +403,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
 #pragma unroll
                             for (int e = 0; e < 4; ++e) h16[f][hb][g2][e] = (half_t)(v[hb][g2][e] - muv[ha][f]);
                         }
-                    sum += __shfl_xor(sum, 16, 64);
-                    sum += __shfl_xor(sum, 32, 64);
+                    sum = sum_rows(sum);
                     const float gm = sum * (1.0f / 64.0f);
                     float m2 = 0.f;
 #pragma unroll
@@ -417,8 +415,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                                 const float d = v[hb][g2][e] - gm;
                                 m2 = fmaf(d, d, m2);
                             }
-                    m2 += __shfl_xor(m2, 16, 64);
-                    m2 += __shfl_xor(m2, 32, 64);
+                    m2 = sum_rows(m2);
                     if (q == 0 && (INTERIOR || m < p.M)) {
                         typedef float f32x2 __attribute__((ext_vector_type(2)));
                         *reinterpret_cast<f32x2*>(p.stats + ((size_t)m * p.stats_ld + sg) * 2) = f32x2{sum, m2};
