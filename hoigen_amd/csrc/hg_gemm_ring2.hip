@@ -124,19 +124,24 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
     for (int i = 0; i < GA; ++i) {
         const int row = (wave * GA + i) * 8 + (lane >> 3);            // 0..127
         const int c = (lane & 7) ^ ((row >> 1) & 7);
-        voffA[i] = row * p.lda * 2 + c * 16;
+        voffA[i] = row * p.lda * 2 + c * 16 - i * 1024;
     }
 #pragma unroll
     for (int i = 0; i < GW; ++i) {
         const int row = (wave * GW + i) * 8 + (lane >> 3);            // 0..255 (W0 = 0..127, W1 = 128..255)
         const int c = (lane & 7) ^ ((row >> 1) & 7);
-        voffW[i] = row * p.K * 2 + c * 16;
+        voffW[i] = row * p.K * 2 + c * 16 - i * 1024;
     }
     // ---- two load streams (A and W are issued in different phases)
     struct Ld { int kt, r, soff, st; };          // K-tile inside its tile, tile, tile origin (bytes), LDS stage offset
     Ld lA{nk - 1, -1, 0, (NST - 1) * STAGE}, lW{nk - 1, -1, 0, (NST - 1) * STAGE};
-    auto advance = [&](Ld& l, bool isA) {
-        if (++l.kt == nk) {
+    // WRAP: 0 = the stream stays inside its tile, 1 = it moves to the next tile, 2 = decide at run time (prologue).
+    // The consumer's K-tile position fixes it: the A stream (distance 2) wraps when K-tile nk-2 is consumed, the W
+    // stream (distance 3) at K-tile nk-3.
+    auto advance = [&](Ld& l, bool isA, auto WRAP_T) {
+        constexpr int WRAP = decltype(WRAP_T)::value;
+        ++l.kt;
+        if (WRAP == 1 || (WRAP == 2 && l.kt == nk)) {
             l.kt = 0;
             ++l.r;
             int tm, tn;
@@ -145,20 +150,32 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
         }
         l.st = l.st == (NST - 1) * STAGE ? 0 : l.st + STAGE;      // stage of stream position g is g % NST
     };
-    auto issue_A = [&]() {
-        advance(lA, true);
-#pragma unroll
-        for (int i = 0; i < GA; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (HG_LDS void*)(smem + lA.st + (wave * GA + i) * 1024), 16,
-                                                     voffA[i], lA.soff + lA.kt * (BK * 2), 0, 0);
+    // all pieces of a wave share one M0 (LDS base): piece i adds its 1 KiB through the instruction's immediate offset,
+    // which the hardware also adds to the global address, so voff*[i] carry -1024 * i
+    auto dma_A = [&](auto I) {
+        constexpr int i = decltype(I)::value;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (HG_LDS void*)(smem + lA.st + wave * GA * 1024), 16, voffA[i],
+                                                 lA.soff + lA.kt * (BK * 2), i * 1024, 0);
     };
-    auto issue_W = [&]() {
-        advance(lW, false);
-#pragma unroll
-        for (int i = 0; i < GW; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (HG_LDS void*)(smem + lW.st + AB + (wave * GW + i) * 1024), 16,
-                                                     voffW[i], lW.soff + lW.kt * (BK * 2), 0, 0);
+    auto dma_W = [&](auto I) {
+        constexpr int i = decltype(I)::value;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (HG_LDS void*)(smem + lW.st + AB + wave * GW * 1024), 16, voffW[i],
+                                                 lW.soff + lW.kt * (BK * 2), i * 1024, 0);
     };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    using P2 = std::integral_constant<int, 2>;
+    using P3 = std::integral_constant<int, 3>;
+    static_assert(GA == 2 && GW == 4, "piece helpers");
+    auto issue_A = [&](auto WRAP_T) {
+        advance(lA, true, WRAP_T);
+        dma_A(P0{}); dma_A(P1{});
+    };
+    auto issue_W = [&](auto WRAP_T) {
+        advance(lW, false, WRAP_T);
+        dma_W(P0{}); dma_W(P1{}); dma_W(P2{}); dma_W(P3{});
+    };
+    using WDYN = std::integral_constant<int, 2>;
 
     // ---- fragment read offsets (row bases are multiples of 16 -> lane-constant swizzle)
     const int sw = (lane >> 1) & 7;
@@ -229,9 +246,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
     // ---- prologue: W(0) A(0) W(1) A(1) W(2); A(2) is issued by the first PA, W(3) by the first PB
-    issue_W(); issue_A();
-    if (S > 1) { issue_W(); issue_A(); }
-    if (S > 2) issue_W();
+    issue_W(WDYN{}); issue_A(WDYN{});
+    if (S > 1) { issue_W(WDYN{}); issue_A(WDYN{}); }
+    if (S > 2) issue_W(WDYN{});
     if (S > 2) wait_vm<NWT>();
     else if (S > 1) wait_vm<GW + GA>();
     else wait_vm<0>();
@@ -269,7 +286,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
             // ---------------- PA: fetch A0, W0, W1 of this K-tile; refill A(g+2); quadrants (A0,W0) (A0,W1)
             read_A(0, st);
             read_W(st);
-            if (KIND < 3 || more) issue_A();              // K-tile g+2 exists
+            if (KIND < 3 || more) issue_A(std::integral_constant<int, KIND == 3 ? 1 : 0>{});   // K-tile g+2 exists
             if constexpr (RESID && KIND == 4) {
                 {      // residual rows of this tile, needed by the epilogue one K-tile later
 #pragma unroll
@@ -302,7 +319,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
             sync_mma();
             // ---------------- PB: fetch A1; refill W(g+3); wait for A,W(g+1); quadrants (A1,W0) (A1,W1)
             read_A(1, st);
-            if (KIND < 2 || more) issue_W();              // K-tile g+3 exists
+            if (KIND < 2 || more) issue_W(std::integral_constant<int, KIND == 2 ? 1 : 0>{});   // K-tile g+3 exists
             SEG_B(0);
             if constexpr (KIND == 0) wait_vm<NWT>();
             else if constexpr (KIND == 1) { if (r > 0) wait_vm<NWT + E>(); else wait_vm<NWT>(); }
