@@ -163,9 +163,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     }
     // ---- load-stream state (wave-uniform): position ld_g, its tile origin and K offset
     int ld_g = -1, ld_kt = nk - 1, ld_r = -1, ld_sA = 0, ld_sW = 0, ld_buf = 0;
-    auto ld_advance = [&]() {
+    // WRAP: 0 = the stream stays inside its tile, 1 = it moves to the next tile, 2 = decide at run time.  In the
+    // two-phase loop the stream (two K-tiles ahead) wraps exactly when K-tile nk-2 is consumed.
+    auto ld_advance = [&](auto WRAP_T) {
+        constexpr int WRAP = decltype(WRAP_T)::value;
         ++ld_g;
-        if (++ld_kt == nk) {
+        ++ld_kt;
+        if (WRAP == 1 || (WRAP == 2 && ld_kt == nk)) {
             ld_kt = 0;
             ++ld_r;
             int tm, tn;
@@ -298,10 +302,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
     // ---- prologue: stream positions 0 and 1 (A1 of position 1 is issued in the first P1)
-    ld_advance();
+    ld_advance(std::integral_constant<int, 2>{});
     issue_A(0, 0, GA); issue_W(0, 0, GB); issue_W(1, 0, GB); issue_A(1, 0, GA);
     if (S > 1) {
-        ld_advance();
+        ld_advance(std::integral_constant<int, 2>{});
         issue_A(0, 0, GA); issue_W(0, 0, GB); issue_W(1, 0, GB);
         if constexpr (PH2) wait_vm<2 * GA + 2 * GB>();   // A0, W0, W1 of position 0 landed
         else wait_vm<N1>();                // A0, W0 of position 0 landed
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             mma(I0{}, I1{});
             sync_mma();
             read_A(1, buf);
-            if (KIND < 2 || more) { ld_advance(); issue_A(0, 0, GA); issue_W(0, 0, GB); issue_W(1, 0, GB); }
+            if (KIND < 2 || more) { ld_advance(std::integral_constant<int, KIND == 2 ? 1 : 0>{}); issue_A(0, 0, GA); issue_W(0, 0, GB); issue_W(1, 0, GB); }
             SEG_B(0);
             if constexpr (KIND == 0) wait_vm<NP>();
             else if constexpr (KIND == 1) { if (post) wait_vm<NP + E>(); else wait_vm<NP>(); }
@@ -478,7 +482,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             sync_mma();
             // ---------------- P2: fetch W1(t); slot A0(t) is free -> A0(t+2); quadrant (0,1)
             read_W(I1{}, buf);
-            if (more) { ld_advance(); issue_A(0, 0, GA); }
+            if (more) { ld_advance(std::integral_constant<int, 2>{}); issue_A(0, 0, GA); }
             SEG_B(0);
             if (!more) wait_vm<0>();              // -> A1(t) landed (read in P3)
             else if (xl) wait_vm<N2 + R>();
