@@ -45,7 +45,10 @@ def ref(a, w, bias, epi, out0):
 
 
 SHAPES = [(1024, 256, 256), (2048, 768, 768), (197 * 16, 2304, 768), (197 * 12 + 5, 768, 3072), (513, 512, 1024),
-          (4096, 3072, 768)]
+          (4096, 3072, 768),
+          # K-tile counts 5 and 6 (the K loop is instantiated per K-tile position: first / middle / last three), a
+          # 256-row-tile case with a ragged last tile, and one with more than 256 tiles of 256x256
+          (777, 512, 320), (2048, 768, 384), (256 * 33 + 100, 2048, 256)]
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)
