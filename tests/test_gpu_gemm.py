@@ -48,7 +48,9 @@ SHAPES = [(1024, 256, 256), (2048, 768, 768), (197 * 16, 2304, 768), (197 * 12 +
           (4096, 3072, 768),
           # K-tile counts 5 and 6 (the K loop is instantiated per K-tile position: first / middle / last three), a
           # 256-row-tile case with a ragged last tile, and one with more than 256 tiles of 256x256
-          (777, 512, 320), (2048, 768, 384), (256 * 33 + 100, 2048, 256)]
+          (777, 512, 320), (2048, 768, 384), (256 * 33 + 100, 2048, 256),
+          # exactly / almost one full round of 256x256 tiles -> the two-phase 256-row kernel, K-tile counts 4 and 5
+          (8192, 2048, 256), (8192 - 60, 2048, 320)]
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)
