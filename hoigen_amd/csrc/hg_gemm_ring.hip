@@ -26,6 +26,17 @@
 // Epilogue stores (and the residual prefetch loads) count in vmcnt too, so the waits that follow them allow
 // for E (R) more.
 //
+// PH2 (the default for 256x256 tiles): the same ring as TWO phases per K-tile - PA fetches A0 W0 W1, refills
+// A1(t+1) and runs quadrants (A0,W0) (A0,W1); PB fetches A1, refills A0 W0 W1(t+2) and runs (A1,W1) (A1,W0); 32 MFMAs
+// per segment, half the barriers, 2GA+2GB DMA instructions in flight at both waits.  Its K-tiles are instantiated by
+// position in the tile (first / middle / second to last / last): the middle of the loop has no run-time conditions,
+// and the load stream wraps to the next tile at a fixed K-tile.
+//
+// Epilogues: bias (+QuickGELU / ReLU) -> fp16 with v_permlane16_swap-paired 16-byte stores; LayerNorm-folded
+// variants (EPI_LN_*: per-row (mean, rstd) staged in LDS by a small DMA, rstd * (acc - mean * cs) + b'); fp32
+// residual with a full prefetch (MF = 2) or a rolling register window (MF = 4), optionally emitting the centred
+// fp16 copy and row statistics (EPI_RESID_LN_F32).  Tiles that lie inside M skip the per-store row masks.
+//
 // The MFMA is issued with W rows as the A operand and activation rows as the B operand, so a lane
 // holds 4 consecutive output columns of one row: 8-byte (fp16) / 16-byte (fp32) epilogue accesses.
 #include <stdio.h>
