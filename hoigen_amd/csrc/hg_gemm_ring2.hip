@@ -538,6 +538,10 @@ static hipError_t launch_ring2_t(const GemmArgs& a, hipStream_t s) {
     int gsz = gsz_env > 0 ? gsz_env : (int)((1536 * 1024) / ((size_t)512 * a.K));
     if (gsz < 3) gsz = 3;
     if (gsz > tiles_n) gsz = tiles_n;
+    if (gsz_env <= 0) {                                  // equal groups: 9 column tiles -> 3 + 3 + 3, not 4 + 4 + 1
+        const int ngroups = (tiles_n + gsz - 1) / gsz;
+        gsz = (tiles_n + ngroups - 1) / ngroups;
+    }
 #ifdef HG_STAMPS
     if (getenv("HG_STAMPS")) {
         const size_t n = (size_t)grid * 8 * 16;
