@@ -31,7 +31,11 @@ import torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 MFMA_PEAK_TFLOPS = 2516.6          # 256 CU x 4096 FLOP/clk/CU x 2.4 GHz (dense fp16/bf16), BASELINE.md §2
-FLOPS_PER_CROP = 35.127e9
+FLOPS_PER_CROP = 35.127e9          # BASELINE.md §2 (every row of every block)
+# The last block runs attention, out-proj and the MLP on the class-token row only (its other 196 rows never reach
+# the embedding; HG_LAST_BLOCK_ROW0=0 computes them anyway).  Those FLOPs are not executed and not counted in e2e_*:
+# per skipped row the Q and out projections, c_fc + c_proj, and its attention row over 197 keys.
+FLOPS_DEAD_ROWS = 196 * (2 * 2 * 768 * 768 + 2 * 2 * 768 * 3072 + 4 * 197 * 768)
 BATCH = 256
 GEMM_CLASS_FC = 1                  # EPI_BIAS_QGELU_F16: the c_fc GEMM (M=B*197, N=3072, K=768)
 
@@ -141,6 +145,8 @@ def main():
     dt = float(t.item())
 
     if rank == 0:
+        row0 = os.environ.get("HG_LAST_BLOCK_ROW0", "1") != "0"
+        flops_per_crop = FLOPS_PER_CROP - (FLOPS_DEAD_ROWS if row0 else 0)
         ms_per_step = dt / args.steps * 1e3
         value = world * args.batch * args.steps / dt
         ach = flops.value / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0
@@ -159,14 +165,17 @@ def main():
             "config": {"workload": "CLIP ViT-B/16 union-region encode (encode_image), 224x224 crops, "
                                    f"batch {args.batch} per GPU, synthetic N(0,1) crops + seeded synthetic weights "
                                    "(BASELINE.json configs[1])",
+                       "last_block": ("K/V for all rows, then class-token rows only (dead rows not computed; "
+                                      "embeddings identical in exact arithmetic)") if row0 else "all rows",
+                       "flops_per_crop_executed": round(flops_per_crop / 1e9, 3),
                        "batch_per_gpu": args.batch, "global_batch": world * args.batch,
                        "parallelism": f"dp{world}" + (" + all_gather[256x512 f32]/step" if world > 1 else "")},
             "roofline": {"bound": "mfma", "kernel": f"gemm_ring (c_fc: M={mnk[0]} N={mnk[1]} K={mnk[2]}, LayerNorm-folded bias+QuickGELU->f16)",
                          "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "avg_kernel_ms": round(avg_ms.value, 4), "launches_timed": launches.value,
-                         "e2e_tflops": round(value / world * FLOPS_PER_CROP / 1e12, 2),
-                         "e2e_frac": round(value / world * FLOPS_PER_CROP / 1e12 / MFMA_PEAK_TFLOPS, 4)},
+                         "e2e_tflops": round(value / world * flops_per_crop / 1e12, 2),
+                         "e2e_frac": round(value / world * flops_per_crop / 1e12 / MFMA_PEAK_TFLOPS, 4)},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

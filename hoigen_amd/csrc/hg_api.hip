@@ -106,7 +106,7 @@ struct hg_ctx {
     Mlp mlp[HG_MAX_SLOTS];
     Cache cache[HG_MAX_CACHE_SLOTS];
     // workspace (grow-only)
-    Buf x, h, qkv, att, fc, head16, tok32, small, i32, ad32, ad16, adkv, mr, mu, stats, pre, pretab;
+    Buf x, h, qkv, att, fc, head16, tok32, small, i32, ad32, ad16, adkv, mr, mu, stats, pre, pretab, cx, ca, ch, cf, cq;
     int max_chunk_img = 256;
     int max_chunk_txt = 640;
     int max_chunk_rows = 32768;
@@ -425,9 +425,17 @@ bool ln_fuse_ok(hg_ctx* c, int M, int D) {
     return gemm_ln_ok(EPI_RESID_LN_F32, r);
 }
 
+// `row0_out` (vision tower without token outputs): only row 0 of every sequence (the class token) leaves the tower,
+// so the LAST block computes K and V for all rows but attention, out-proj and the MLP for the n_seq class rows only
+// (a dense [n_seq, D] stream, returned through *row0_out); all other rows of that block never reach any output.
+// HG_LAST_BLOCK_ROW0=0 runs the last block on every row like the others.
 int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, int D, int heads, bool causal,
-               hipStream_t s, float* trace, int trace_stride, const AdapterCall* ac, bool ln_fold) {
+               hipStream_t s, float* trace, int trace_stride, const AdapterCall* ac, bool ln_fold,
+               const float** row0_out = nullptr) {
     const int M = n_seq * L;
+    const char* row0_e = getenv("HG_LAST_BLOCK_ROW0");      // read per call: the tests switch it
+    const bool row0_env = !(row0_e && row0_e[0] == '0');
+    if (row0_out) *row0_out = nullptr;
     float* x = (float*)c->x.p;
     half_t* h = (half_t*)c->h.p;
     half_t* qkv = (half_t*)c->qkv.p;
@@ -455,15 +463,48 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
             int rc = run_adapter(c, c->vit.adapters[i], n_seq, L, D, *ac, s);
             if (rc) return rc;
         }
+        const bool row0_last = row0_out && row0_env && !causal && !adapters && i + 1 == blocks.size();
+        // in_proj rows [qoff, 3D): the class-rows-only last block needs K and V of every row but Q of row 0 only
+        const size_t qoff = row0_last ? D : 0;
         GemmArgs g{};
-        g.A = h; g.lda = D; g.out = qkv; g.ldc = 3 * D; g.M = M; g.N = 3 * D; g.K = D;
+        g.A = h; g.lda = D; g.out = qkv + qoff; g.ldc = 3 * D; g.M = M; g.N = 3 * D - (int)qoff; g.K = D;
         if (fuse) {
-            g.W = b.wf_qkv; g.bias = b.bf_qkv; g.cs = b.cs_qkv; g.mr = mr;
+            g.W = b.wf_qkv + qoff * D; g.bias = b.bf_qkv + qoff; g.cs = b.cs_qkv + qoff; g.mr = mr;
             HG_HIP(gemm(c, EPI_LN_BIAS_F16, g, s));
         } else {
             HG_HIP(launch_layernorm_f16(x, b.ln1_w, b.ln1_b, h, M, D, nullptr, 0, 1, s));
-            g.W = b.w_qkv; g.bias = b.b_qkv;
+            g.W = b.w_qkv + qoff * D; g.bias = b.b_qkv + qoff;
             HG_HIP(gemm(c, EPI_BIAS_F16, g, s));
+        }
+        if (row0_last) {
+            int rc = ensure(c, c->cx, (size_t)n_seq * D * 4);
+            if (!rc) rc = ensure(c, c->ca, rup(n_seq, 256) * D * 2);
+            if (!rc) rc = ensure(c, c->ch, rup(n_seq, 256) * D * 2);
+            if (!rc) rc = ensure(c, c->cf, rup(n_seq, 256) * (size_t)4 * D * 2);
+            if (!rc) rc = ensure(c, c->cq, rup(n_seq, 256) * D * 2);
+            if (rc) return rc;
+            float* cx = (float*)c->cx.p;
+            half_t *ca = (half_t*)c->ca.p, *ch = (half_t*)c->ch.p, *cf = (half_t*)c->cf.p, *cq = (half_t*)c->cq.p;
+            // Q of the class rows: ln_1 on those rows, then the first D rows of in_proj
+            HG_HIP(launch_layernorm_f16(x, b.ln1_w, b.ln1_b, ch, n_seq, D, nullptr, 0, L, s));
+            g = GemmArgs{};
+            g.A = ch; g.lda = D; g.W = b.w_qkv; g.bias = b.b_qkv; g.out = cq; g.ldc = D; g.M = n_seq; g.N = D; g.K = D;
+            HG_HIP(gemm(c, EPI_BIAS_F16, g, s));
+            HG_HIP(launch_attention_row0(qkv, cq, ca, n_seq, L, heads, s));
+            HG_HIP(launch_copy_rows(x, cx, n_seq, L, D, s));
+            g = GemmArgs{};
+            g.A = ca; g.lda = D; g.W = b.w_out; g.bias = b.b_out; g.out = cx; g.ldc = D; g.M = n_seq; g.N = D; g.K = D;
+            HG_HIP(gemm(c, EPI_BIAS_RESID_F32, g, s));
+            HG_HIP(launch_layernorm_f16(cx, b.ln2_w, b.ln2_b, ch, n_seq, D, nullptr, 0, 1, s));
+            g = GemmArgs{};
+            g.A = ch; g.lda = D; g.W = b.w_fc; g.bias = b.b_fc; g.out = cf; g.ldc = 4 * D; g.M = n_seq; g.N = 4 * D; g.K = D;
+            HG_HIP(gemm(c, EPI_BIAS_QGELU_F16, g, s));
+            g = GemmArgs{};
+            g.A = cf; g.lda = 4 * D; g.W = b.w_proj; g.bias = b.b_proj; g.out = cx; g.ldc = D; g.M = n_seq; g.N = D; g.K = 4 * D;
+            HG_HIP(gemm(c, EPI_BIAS_RESID_F32, g, s));
+            if (trace) HG_HIP(launch_copy_rows(cx, trace + (size_t)(i + 1) * trace_stride, n_seq, 1, D, s));
+            *row0_out = cx;
+            break;
         }
         HG_HIP(launch_attention(qkv, att, n_seq, L, heads, causal, s));
         g = GemmArgs{};
@@ -567,7 +608,7 @@ void hg_destroy(hg_ctx* c) {
     for (auto& m : c->mlp) free_all(m.owned);
     for (auto& m : c->cache) free_all(m.owned);
     Buf* bufs[] = {&c->x, &c->h, &c->qkv, &c->att, &c->fc, &c->head16, &c->tok32, &c->small, &c->i32,
-                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->stats, &c->pre, &c->pretab};
+                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq};
     for (Buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
@@ -708,7 +749,7 @@ int hg_profile_end(hg_ctx* c, double* avg_ms, int32_t* launches, double* flops_p
 int hg_workspace_bytes(hg_ctx* c, uint64_t* bytes) {
     if (!c || !bytes) return HG_ERR_INVALID;
     Buf* bufs[] = {&c->x, &c->h, &c->qkv, &c->att, &c->fc, &c->head16, &c->tok32, &c->small, &c->i32,
-                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->stats, &c->pre, &c->pretab};
+                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq};
     uint64_t t = 0;
     for (Buf* b : bufs) t += b->bytes;
     *bytes = t;
@@ -1038,12 +1079,14 @@ static int encode_image_impl(hg_ctx* c, const float* x_nchw, const float* priors
         ac.priors = priors ? priors + (size_t)b0 * N * 64 : nullptr;
         ac.mask = mask ? mask + (size_t)b0 * N : nullptr;
         ac.N = N;
-        rc = run_blocks(c, v.blocks, Bc, L, D, v.heads, false, s, tr, tstride, &ac, true);
+        const float* row0 = nullptr;      // dense class-token rows when the last block ran on them only
+        rc = run_blocks(c, v.blocks, Bc, L, D, v.heads, false, s, tr, tstride, &ac, true, variant_c ? nullptr : &row0);
         if (rc) return rc;
         half_t* h16 = (half_t*)c->head16.p;
         if (!variant_c) {
             // ln_post(x[:,0,:]) @ proj   (clipnet/model.py:231-234)
-            HG_HIP(launch_layernorm_f16(x, v.lnpost_w, v.lnpost_b, h16, Bc, D, nullptr, 0, L, s));
+            if (row0) HG_HIP(launch_layernorm_f16(row0, v.lnpost_w, v.lnpost_b, h16, Bc, D, nullptr, 0, 1, s));
+            else HG_HIP(launch_layernorm_f16(x, v.lnpost_w, v.lnpost_b, h16, Bc, D, nullptr, 0, L, s));
             g = GemmArgs{};
             g.A = h16; g.lda = D; g.W = v.w_projT; g.out = out + (size_t)b0 * E; g.ldc = E; g.M = Bc; g.N = E; g.K = D;
             HG_HIP(gemm(c, EPI_BIAS_F32, g, s));

@@ -26,9 +26,12 @@ static constexpr int TILEB = 32 * ROWB;  // bytes per 32-key tile
 __device__ __forceinline__ int swz_k(int row) { return (row >> 1) & 7; }          // b128 row reads
 __device__ __forceinline__ int swz_v(int row) { return ((row >> 1) & 1) << 2; }   // tr_b16 reads
 
-template <bool CAUSAL>
+// ROW0: only query 0 of every sequence is wanted (the class token in the last block of the vision tower, whose other
+// rows never reach the output): every wave helps to stage K and V, wave 0 runs its query tile exactly as in the full
+// kernel (so the row is bit-identical to the full kernel's) and the result goes to a dense [n_seq, D] matrix.
+template <bool CAUSAL, bool ROW0>
 __global__ __launch_bounds__(448) void attention_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
-                                                        int L, int heads, int nkt) {
+                                                        int L, int heads, int nkt, const half_t* __restrict__ q0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
     char* Vs = smem + nkt * TILEB;
@@ -54,12 +57,16 @@ __global__ __launch_bounds__(448) void attention_kernel(const half_t* __restrict
     const int qt = wave;
     const int qcol = lane & 31, hh = lane >> 5;
     const int q = qt * 32 + qcol;
-    const half_t* qp = base + (size_t)(q < L ? q : L - 1) * ld + hh * 8;
+    // ROW0: every lane's query aliases the sequence's row of the dense q0 matrix (only query 0 is stored)
+    const half_t* qp = ROW0 ? q0 + (size_t)seq * D + head * HD + hh * 8 : base + (size_t)(q < L ? q : L - 1) * ld + hh * 8;
     half8 qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const half8*>(qp + ks * 16);
 
     __syncthreads();   // K/V landed (the barrier's fence waits for the LDS-DMA: vmcnt(0))
+    if constexpr (ROW0) {
+        if (wave != 0) return;
+    }
 
     // lane-constant LDS offsets
     int k_off[4];
@@ -152,8 +159,8 @@ __global__ __launch_bounds__(448) void attention_kernel(const half_t* __restrict
     lsum += __shfl_xor(lsum, 32, 64);
     const float inv = 1.0f / lsum;
     // ---- store: lane = query q, d = dt*32 + (r&3) + 8*(r>>2) + 4*hh
-    if (q < L) {
-        half_t* op = out + ((size_t)seq * L + q) * D + head * HD;
+    if (ROW0 ? q == 0 : q < L) {
+        half_t* op = out + (ROW0 ? (size_t)seq : (size_t)seq * L + q) * D + head * HD;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -166,18 +173,19 @@ __global__ __launch_bounds__(448) void attention_kernel(const half_t* __restrict
     }
 }
 
-template <bool CAUSAL>
-static hipError_t launch_t(const half_t* qkv, half_t* out, int n_seq, int L, int heads, hipStream_t s) {
+template <bool CAUSAL, bool ROW0 = false>
+static hipError_t launch_t(const half_t* qkv, half_t* out, int n_seq, int L, int heads, hipStream_t s,
+                           const half_t* q0 = nullptr) {
     const int nkt = (L + 31) / 32;
     const int lds = 2 * nkt * TILEB;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<CAUSAL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<CAUSAL, ROW0>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 7 * TILEB);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((attention_kernel<CAUSAL>), dim3(n_seq * heads), dim3(64 * nkt), lds, s, qkv, out, L, heads, nkt);
+    hipLaunchKernelGGL((attention_kernel<CAUSAL, ROW0>), dim3(n_seq * heads), dim3(64 * nkt), lds, s, qkv, out, L, heads, nkt, q0);
     return hipGetLastError();
 }
 
@@ -186,6 +194,13 @@ hipError_t launch_attention(const half_t* qkv, half_t* out, int n_seq, int L, in
     if (n_seq <= 0) return hipSuccess;
     if (L < 1 || L > 224) return hipErrorInvalidValue;
     return causal ? launch_t<true>(qkv, out, n_seq, L, heads, s) : launch_t<false>(qkv, out, n_seq, L, heads, s);
+}
+
+hipError_t launch_attention_row0(const half_t* qkv, const half_t* q0, half_t* out, int n_seq, int L, int heads,
+                                 hipStream_t s) {
+    if (n_seq <= 0) return hipSuccess;
+    if (L < 1 || L > 224 || !q0) return hipErrorInvalidValue;
+    return launch_t<false, true>(qkv, out, n_seq, L, heads, s, q0);
 }
 
 }  // namespace hg

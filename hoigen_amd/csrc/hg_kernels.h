@@ -65,6 +65,10 @@ hipError_t launch_gemm_simple(int epi, const GemmArgs& a, hipStream_t s);
 // out fp16 [n_seq*L, D].  L <= 224.
 hipError_t launch_attention(const half_t* qkv, half_t* out, int n_seq, int L, int heads, bool causal,
                             hipStream_t s);
+// non-causal attention of query row 0 of every sequence only: K and V from qkv [n_seq*L, 3*heads*64], the queries
+// from q0 [n_seq, heads*64] (dense), out [n_seq, heads*64] (dense)
+hipError_t launch_attention_row0(const half_t* qkv, const half_t* q0, half_t* out, int n_seq, int L, int heads,
+                                 hipStream_t s);
 
 // ---- elementwise / row kernels ---------------------------------------------------------------
 // LayerNorm over rows of fp32 x (eps 1e-5, biased variance; clipnet/model.py:153-159).
