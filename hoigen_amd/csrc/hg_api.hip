@@ -425,13 +425,14 @@ bool ln_fuse_ok(hg_ctx* c, int M, int D) {
     return gemm_ln_ok(EPI_RESID_LN_F32, r);
 }
 
-// `row0_out` (vision tower without token outputs): only row 0 of every sequence (the class token) leaves the tower,
-// so the LAST block computes K and V for all rows but attention, out-proj and the MLP for the n_seq class rows only
-// (a dense [n_seq, D] stream, returned through *row0_out); all other rows of that block never reach any output.
+// `row0_out` (towers without token outputs): only ONE row of every sequence leaves the tower - row sel[seq] (the EOT
+// token of the text tower) or row 0 when sel is null (the class token of the vision tower) - so the LAST block
+// computes K and V for all rows but Q, attention, out-proj and the MLP for those n_seq rows only (a dense
+// [n_seq, D] stream, returned through *row0_out); all other rows of that block never reach any output.
 // HG_LAST_BLOCK_ROW0=0 runs the last block on every row like the others.
 int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, int D, int heads, bool causal,
                hipStream_t s, float* trace, int trace_stride, const AdapterCall* ac, bool ln_fold,
-               const float** row0_out = nullptr) {
+               const float** row0_out = nullptr, const int32_t* sel = nullptr) {
     const int M = n_seq * L;
     const char* row0_e = getenv("HG_LAST_BLOCK_ROW0");      // read per call: the tests switch it
     const bool row0_env = !(row0_e && row0_e[0] == '0');
@@ -463,7 +464,7 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
             int rc = run_adapter(c, c->vit.adapters[i], n_seq, L, D, *ac, s);
             if (rc) return rc;
         }
-        const bool row0_last = row0_out && row0_env && !causal && !adapters && i + 1 == blocks.size();
+        const bool row0_last = row0_out && row0_env && !adapters && i + 1 == blocks.size();
         // in_proj rows [qoff, 3D): the class-rows-only last block needs K and V of every row but Q of row 0 only
         const size_t qoff = row0_last ? D : 0;
         GemmArgs g{};
@@ -485,13 +486,14 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
             if (rc) return rc;
             float* cx = (float*)c->cx.p;
             half_t *ca = (half_t*)c->ca.p, *ch = (half_t*)c->ch.p, *cf = (half_t*)c->cf.p, *cq = (half_t*)c->cq.p;
-            // Q of the class rows: ln_1 on those rows, then the first D rows of in_proj
-            HG_HIP(launch_layernorm_f16(x, b.ln1_w, b.ln1_b, ch, n_seq, D, nullptr, 0, L, s));
+            // Q of the selected rows: ln_1 on those rows, then the first D rows of in_proj
+            if (sel) HG_HIP(launch_layernorm_f16(x, b.ln1_w, b.ln1_b, ch, n_seq, D, sel, L, 0, s));
+            else HG_HIP(launch_layernorm_f16(x, b.ln1_w, b.ln1_b, ch, n_seq, D, nullptr, 0, L, s));
             g = GemmArgs{};
             g.A = ch; g.lda = D; g.W = b.w_qkv; g.bias = b.b_qkv; g.out = cq; g.ldc = D; g.M = n_seq; g.N = D; g.K = D;
             HG_HIP(gemm(c, EPI_BIAS_F16, g, s));
-            HG_HIP(launch_attention_row0(qkv, cq, ca, n_seq, L, heads, s));
-            HG_HIP(launch_copy_rows(x, cx, n_seq, L, D, s));
+            HG_HIP(launch_attention_row0(qkv, cq, sel, ca, n_seq, L, heads, causal, s));
+            HG_HIP(launch_copy_rows(x, cx, n_seq, L, D, s, sel));
             g = GemmArgs{};
             g.A = ca; g.lda = D; g.W = b.w_out; g.bias = b.b_out; g.out = cx; g.ldc = D; g.M = n_seq; g.N = D; g.K = D;
             HG_HIP(gemm(c, EPI_BIAS_RESID_F32, g, s));
@@ -1121,12 +1123,14 @@ static int text_tail(hg_ctx* c, int Tc, int Leff, const int32_t* eot, float* out
     const int D = t.D, E = t.E;
     // the text tower keeps the separate LayerNorm: folding moved its parity error from 6.5e-4 to 7.4e-4 (worst
     // prompt 9.0e-4) of the 1e-3 budget, for no measurable time gain at these sizes
-    int rc = run_blocks(c, t.blocks, Tc, Leff, D, t.heads, true, s, nullptr, 0, nullptr, false);
+    const float* rows = nullptr;      // dense EOT rows when the last block ran on them only
+    int rc = run_blocks(c, t.blocks, Tc, Leff, D, t.heads, true, s, nullptr, 0, nullptr, false, &rows, eot);
     if (rc) return rc;
     half_t* h16 = (half_t*)c->head16.p;
     // ln_final, select the EOT row, @ text_projection (clipnet/model.py:346-350); LN is row-wise so
     // selecting before normalising is identical
-    HG_HIP(launch_layernorm_f16((const float*)c->x.p, t.lnf_w, t.lnf_b, h16, Tc, D, eot, Leff, 0, s));
+    if (rows) HG_HIP(launch_layernorm_f16(rows, t.lnf_w, t.lnf_b, h16, Tc, D, nullptr, 0, 1, s));
+    else HG_HIP(launch_layernorm_f16((const float*)c->x.p, t.lnf_w, t.lnf_b, h16, Tc, D, eot, Leff, 0, s));
     GemmArgs g{};
     g.A = h16; g.lda = D; g.W = t.w_projT; g.out = out; g.ldc = E; g.M = Tc; g.N = E; g.K = D;
     HG_HIP(gemm(c, EPI_BIAS_F32, g, s));

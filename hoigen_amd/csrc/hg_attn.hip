@@ -26,12 +26,15 @@ static constexpr int TILEB = 32 * ROWB;  // bytes per 32-key tile
 __device__ __forceinline__ int swz_k(int row) { return (row >> 1) & 7; }          // b128 row reads
 __device__ __forceinline__ int swz_v(int row) { return ((row >> 1) & 1) << 2; }   // tr_b16 reads
 
-// ROW0: only query 0 of every sequence is wanted (the class token in the last block of the vision tower, whose other
-// rows never reach the output): every wave helps to stage K and V, wave 0 runs its query tile exactly as in the full
-// kernel (so the row is bit-identical to the full kernel's) and the result goes to a dense [n_seq, D] matrix.
+// ROW0: only ONE query of every sequence is wanted - row sel[seq] (row 0 when sel is null): the class token in the
+// last block of the vision tower, the EOT token in the last block of the text tower; the block's other rows never
+// reach the output.  Every wave helps to stage K and V, wave 0 then runs that query (all 32 lanes of the tile alias
+// it) through the same instruction sequence as the full kernel, so the row is bit-identical to the full kernel's; the
+// query comes from the dense matrix q0 [n_seq, D] and the result goes to a dense [n_seq, D] matrix.
 template <bool CAUSAL, bool ROW0>
 __global__ __launch_bounds__(448) void attention_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
-                                                        int L, int heads, int nkt, const half_t* __restrict__ q0) {
+                                                        int L, int heads, int nkt, const half_t* __restrict__ q0,
+                                                        const int32_t* __restrict__ sel) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
     char* Vs = smem + nkt * TILEB;
@@ -54,9 +57,11 @@ __global__ __launch_bounds__(448) void attention_kernel(const half_t* __restrict
     }
 
     // ---- this wave's query tile; Q fragments straight from global (B operand: lane = query, k = d)
-    const int qt = wave;
+    int qsel = ROW0 && sel ? __builtin_amdgcn_readfirstlane(sel[seq]) : 0;
+    qsel = qsel < 0 ? 0 : (qsel >= L ? L - 1 : qsel);      // caller error guard, as in layernorm_kernel
+    const int qt = ROW0 ? (qsel >> 5) : wave;
     const int qcol = lane & 31, hh = lane >> 5;
-    const int q = qt * 32 + qcol;
+    const int q = ROW0 ? qsel : qt * 32 + qcol;
     // ROW0: every lane's query aliases the sequence's row of the dense q0 matrix (only query 0 is stored)
     const half_t* qp = ROW0 ? q0 + (size_t)seq * D + head * HD + hh * 8 : base + (size_t)(q < L ? q : L - 1) * ld + hh * 8;
     half8 qf[4];
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(448) void attention_kernel(const half_t* __restrict
     lsum += __shfl_xor(lsum, 32, 64);
     const float inv = 1.0f / lsum;
     // ---- store: lane = query q, d = dt*32 + (r&3) + 8*(r>>2) + 4*hh
-    if (ROW0 ? q == 0 : q < L) {
+    if (ROW0 ? qcol == 0 : q < L) {
         half_t* op = out + (ROW0 ? (size_t)seq : (size_t)seq * L + q) * D + head * HD;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(448) void attention_kernel(const half_t* __restrict
 
 template <bool CAUSAL, bool ROW0 = false>
 static hipError_t launch_t(const half_t* qkv, half_t* out, int n_seq, int L, int heads, hipStream_t s,
-                           const half_t* q0 = nullptr) {
+                           const half_t* q0 = nullptr, const int32_t* sel = nullptr) {
     const int nkt = (L + 31) / 32;
     const int lds = 2 * nkt * TILEB;
     static bool attr_set = false;
@@ -185,7 +190,7 @@ static hipError_t launch_t(const half_t* qkv, half_t* out, int n_seq, int L, int
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((attention_kernel<CAUSAL, ROW0>), dim3(n_seq * heads), dim3(64 * nkt), lds, s, qkv, out, L, heads, nkt, q0);
+    hipLaunchKernelGGL((attention_kernel<CAUSAL, ROW0>), dim3(n_seq * heads), dim3(64 * nkt), lds, s, qkv, out, L, heads, nkt, q0, sel);
     return hipGetLastError();
 }
 
@@ -196,11 +201,12 @@ hipError_t launch_attention(const half_t* qkv, half_t* out, int n_seq, int L, in
     return causal ? launch_t<true>(qkv, out, n_seq, L, heads, s) : launch_t<false>(qkv, out, n_seq, L, heads, s);
 }
 
-hipError_t launch_attention_row0(const half_t* qkv, const half_t* q0, half_t* out, int n_seq, int L, int heads,
-                                 hipStream_t s) {
+hipError_t launch_attention_row0(const half_t* qkv, const half_t* q0, const int32_t* sel, half_t* out, int n_seq, int L,
+                                 int heads, bool causal, hipStream_t s) {
     if (n_seq <= 0) return hipSuccess;
     if (L < 1 || L > 224 || !q0) return hipErrorInvalidValue;
-    return launch_t<false, true>(qkv, out, n_seq, L, heads, s, q0);
+    return causal ? launch_t<true, true>(qkv, out, n_seq, L, heads, s, q0, sel)
+                  : launch_t<false, true>(qkv, out, n_seq, L, heads, s, q0, sel);
 }
 
 }  // namespace hg

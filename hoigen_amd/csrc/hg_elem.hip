@@ -414,15 +414,19 @@ hipError_t launch_split_global_local(const float* tok, float* glob, float* local
     return hipGetLastError();
 }
 
-__global__ void copy_rows_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int row_stride, int D) {
+__global__ void copy_rows_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int row_stride, int D,
+                                 const int32_t* __restrict__ gather) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= B * D) return;
     const int b = i / D, d = i - b * D;
-    out[i] = x[(size_t)b * row_stride * D + d];
+    int g = gather ? gather[b] : 0;
+    g = g < 0 ? 0 : (g >= row_stride ? row_stride - 1 : g);      // caller error guard, as in layernorm_kernel
+    out[i] = x[((size_t)b * row_stride + g) * D + d];
 }
-hipError_t launch_copy_rows(const float* x, float* out, int B, int row_stride, int D, hipStream_t s) {
+hipError_t launch_copy_rows(const float* x, float* out, int B, int row_stride, int D, hipStream_t s,
+                            const int32_t* gather) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(copy_rows_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, x, out, B, row_stride, D);
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, x, out, B, row_stride, D, gather);
     return hipGetLastError();
 }
 // first N columns of a [R, ld] matrix -> dense [R, N]

@@ -65,10 +65,10 @@ hipError_t launch_gemm_simple(int epi, const GemmArgs& a, hipStream_t s);
 // out fp16 [n_seq*L, D].  L <= 224.
 hipError_t launch_attention(const half_t* qkv, half_t* out, int n_seq, int L, int heads, bool causal,
                             hipStream_t s);
-// non-causal attention of query row 0 of every sequence only: K and V from qkv [n_seq*L, 3*heads*64], the queries
-// from q0 [n_seq, heads*64] (dense), out [n_seq, heads*64] (dense)
-hipError_t launch_attention_row0(const half_t* qkv, const half_t* q0, half_t* out, int n_seq, int L, int heads,
-                                 hipStream_t s);
+// attention of ONE query row per sequence (row sel[seq], row 0 when sel is null; sel[seq] < L): K and V from
+// qkv [n_seq*L, 3*heads*64], the queries from q0 [n_seq, heads*64] (dense), out [n_seq, heads*64] (dense)
+hipError_t launch_attention_row0(const half_t* qkv, const half_t* q0, const int32_t* sel, half_t* out, int n_seq, int L,
+                                 int heads, bool causal, hipStream_t s);
 
 // ---- elementwise / row kernels ---------------------------------------------------------------
 // LayerNorm over rows of fp32 x (eps 1e-5, biased variance; clipnet/model.py:153-159).
@@ -106,7 +106,8 @@ hipError_t launch_vae_loss(const float* recon, const float* x, const float* mean
 // tokens [B*L, E] fp32 -> global [B,E] (token 0) and local [B,E,g,g] (tokens 1..), NCHW
 hipError_t launch_split_global_local(const float* tok, float* glob, float* local, int B, int L, int E,
                                      hipStream_t s);
-hipError_t launch_copy_rows(const float* x, float* out, int B, int row_stride, int D, hipStream_t s);
+hipError_t launch_copy_rows(const float* x, float* out, int B, int row_stride, int D, hipStream_t s,
+                            const int32_t* gather = nullptr);   // row b*row_stride (+ gather[b])
 // first N columns of a [R, ld] fp32 matrix -> dense [R, N]
 hipError_t launch_copy_cols(const float* x, int ld, float* out, int R, int N, hipStream_t s);
 // ---- LayerNorm folding support (DESIGN.md §4 "LayerNorm folded into the GEMMs")

@@ -344,7 +344,7 @@ def test_layernorm_folding_matches_separate_layernorm(fullA, g0, monkeypatch):
     assert torch.equal(outs["1"][1], outs["0"][1]), "the text tower does not fold LayerNorm"
 
 
-def test_last_block_on_class_rows_only_matches_full_last_block(fullA, monkeypatch):
+def test_last_block_on_class_rows_only_matches_full_last_block(fullA, g0, monkeypatch):
     """encode_image returns ln_post(x[:, 0]) @ proj, so after K and V the last block only needs the class-token row of
     every crop; HG_LAST_BLOCK_ROW0=0 runs it on all 197 rows like the reference does.  Same result
     within the parity tolerance, both within it of the reference, and the per-block trace agrees."""
@@ -352,9 +352,15 @@ def test_last_block_on_class_rows_only_matches_full_last_block(fullA, monkeypatc
     torch.manual_seed(5)
     img = torch.cat([torch.from_numpy(synth.crops(4, 224, seed=1234)).to(dev()), torch.randn(36, 3, 224, 224, device=dev())])
     outs = {}
+    ids = clip.tokenize(g0["obj81"]["text"]).to(dev())
+    txt = {}
     for mode in ("1", "0"):
         monkeypatch.setenv("HG_LAST_BLOCK_ROW0", mode)
         outs[mode] = fullA.visual.forward_trace(img)
+        for trunc in (True, False):
+            fullA.truncate_text = trunc
+            txt[mode, trunc] = fullA.encode_text(ids).float()
+        fullA.truncate_text = True
         e = check(outs[mode][0][:4], g["encode_image"], what=f"encode_image HG_LAST_BLOCK_ROW0={mode}")
         print(f"\nencode_image rel-L2 vs reference, HG_LAST_BLOCK_ROW0={mode}: {e:.3e}")
     monkeypatch.delenv("HG_LAST_BLOCK_ROW0")
@@ -362,6 +368,10 @@ def test_last_block_on_class_rows_only_matches_full_last_block(fullA, monkeypatc
     check(outs["1"][0], outs["0"][0].cpu().numpy(), what="class rows only vs full last block (embedding)")
     assert torch.equal(outs["1"][1][:-1], outs["0"][1][:-1]), "blocks before the last one are untouched"
     check(outs["1"][1][-1], outs["0"][1][-1].cpu().numpy(), what="class rows after the last block")
+    # the text tower (EOT rows) keeps the separate LayerNorm in both modes, and the 128x128 GEMM kernel of the dense
+    # rows accumulates in the same order as the ring kernels: bit-identical
+    for trunc in (True, False):
+        assert torch.equal(txt["1", trunc], txt["0", trunc]), f"text tower, EOT rows only (truncate={trunc})"
 
 
 def test_text_truncation_is_exact_selection(fullA, g0):
