@@ -36,8 +36,11 @@ __global__ __launch_bounds__(448) void attention_kernel(const half_t* __restrict
                                                         int L, int heads, int nkt, const half_t* __restrict__ q0,
                                                         const int32_t* __restrict__ sel) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // K and V rows 0 .. rs-1 are staged, rs = L rounded up to 16 (the last key tile may be half present: its second
+    // 16-key step is skipped in P V, its missing K rows read into the V region and are masked)
+    const int rs = (L + 15) & ~15;
     char* Ks = smem;
-    char* Vs = smem + nkt * TILEB;
+    char* Vs = smem + rs * ROWB;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwaves = blockDim.x >> 6;
@@ -47,7 +50,7 @@ __global__ __launch_bounds__(448) void attention_kernel(const half_t* __restrict
     const half_t* base = qkv + (size_t)seq * L * ld + head * HD;
 
     // ---- stage K and V: piece = 8 rows x 128 B; lane -> (row = l>>3, chunk' = l&7)
-    for (int piece = wave; piece < nkt * 4; piece += nwaves) {
+    for (int piece = wave; piece < rs / 8; piece += nwaves) {
         const int row = piece * 8 + (lane >> 3);
         const int src_row = row < L ? row : L - 1;
         const half_t* rp = base + (size_t)src_row * ld;
@@ -146,6 +149,7 @@ __global__ __launch_bounds__(448) void attention_kernel(const half_t* __restrict
         const char* vb = Vs + kt * TILEB;
 #pragma unroll
         for (int sstep = 0; sstep < 2; ++sstep) {
+            if (sstep == 1 && kt * 32 + 16 >= rs) break;      // keys beyond the staged rows (all masked): wave-uniform
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
                 const char* va = vb + sstep * (16 * ROWB) + v_off[dt];
@@ -182,7 +186,7 @@ template <bool CAUSAL, bool ROW0 = false>
 static hipError_t launch_t(const half_t* qkv, half_t* out, int n_seq, int L, int heads, hipStream_t s,
                            const half_t* q0 = nullptr, const int32_t* sel = nullptr) {
     const int nkt = (L + 31) / 32;
-    const int lds = 2 * nkt * TILEB;
+    const int lds = 2 * ((L + 15) & ~15) * ROWB;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<CAUSAL, ROW0>),
