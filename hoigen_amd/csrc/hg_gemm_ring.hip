@@ -546,6 +546,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             constexpr bool INTERIOR = decltype(INTERIOR_T)::value;
             const int q = lane >> 4;
             half_t* outp = reinterpret_cast<half_t*>(p.out);
+            f32x4 gk = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_LN_BIAS_QGELU_F16) gk = quick_gelu_consts();
+            (void)gk;
 #pragma unroll
             for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
@@ -574,8 +577,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                                 vy = acc[ha][hb][f + 1][g2] + bv;
                             }
                             if constexpr (EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_LN_BIAS_QGELU_F16) {
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) { vx[r] = quick_gelu_r(vx[r]); vy[r] = quick_gelu_r(vy[r]); }
+                                vx = quick_gelu4(vx, gk);
+                                vy = quick_gelu4(vy, gk);
                             }
                             if constexpr (EPI == EPI_BIAS_RELU_F16) {
 #pragma unroll
