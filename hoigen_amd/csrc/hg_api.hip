@@ -714,6 +714,30 @@ int hg_test_gemm(hg_ctx* c, const float* a, const float* w, const float* bias, f
     return HG_OK;
 }
 
+int hg_test_attention(hg_ctx* c, const float* qkv, const float* q0, const int32_t* sel, int n_seq, int L, int heads,
+                      int causal, float* out, void* stream) {
+    if (!c || !qkv || !out || n_seq <= 0 || L < 1 || L > 224 || heads < 1) return HG_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    HG_HIP(hipSetDevice(c->device));
+    const int D = heads * 64;
+    const size_t M = (size_t)n_seq * L;
+    int rc = ensure(c, c->qkv, rup(M, 256) * 3 * D * 2);
+    if (!rc) rc = ensure(c, c->att, rup(M, 256) * D * 2);
+    if (!rc && q0) rc = ensure(c, c->cq, rup(n_seq, 256) * (size_t)D * 2);
+    if (rc) return rc;
+    HG_HIP(launch_f32_to_f16(qkv, (half_t*)c->qkv.p, M * 3 * D, s));
+    if (q0) {      // one query row per sequence (row sel[seq], or 0): out [n_seq, D]
+        HG_HIP(launch_f32_to_f16(q0, (half_t*)c->cq.p, (size_t)n_seq * D, s));
+        HG_HIP(launch_attention_row0((const half_t*)c->qkv.p, (const half_t*)c->cq.p, sel, (half_t*)c->att.p, n_seq, L,
+                                     heads, causal != 0, s));
+        HG_HIP(launch_f16_to_f32((const half_t*)c->att.p, out, (size_t)n_seq * D, s));
+    } else {
+        HG_HIP(launch_attention((const half_t*)c->qkv.p, (half_t*)c->att.p, n_seq, L, heads, causal != 0, s));
+        HG_HIP(launch_f16_to_f32((const half_t*)c->att.p, out, M * D, s));
+    }
+    return HG_OK;
+}
+
 int hg_profile_begin(hg_ctx* c, int gemm_class, int max_launches) {
     if (!c || max_launches < 0) return HG_ERR_INVALID;
     HG_HIP(hipSetDevice(c->device));

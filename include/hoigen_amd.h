@@ -233,6 +233,12 @@ int hg_profile_begin(hg_ctx*, int gemm_class, int max_launches);
  * 3 bias+residual(f32), 4 bias->f32, 6 bias+ReLU->f32.  kernel: 0 auto, 1 simple 128x128, 2 persistent ring. */
 int hg_test_gemm(hg_ctx*, const float* a, const float* w, const float* bias, float* out, int M, int N, int K,
                  int epi, int kernel, void* stream);
+/* Test hook for the attention kernels (clipnet/model.py:171,181-183: the SDPA inside nn.MultiheadAttention, head_dim
+ * 64): qkv [n_seq*L, 3*heads*64] fp32 on the device (rounded to fp16 inside).  q0 == NULL: full attention, out
+ * [n_seq*L, heads*64].  q0 != NULL: [n_seq, heads*64] queries of ONE row per sequence (row sel[seq], device int32, or
+ * row 0 when sel is NULL - the row index only matters for the causal mask), out [n_seq, heads*64]. */
+int hg_test_attention(hg_ctx*, const float* qkv, const float* q0, const int32_t* sel, int n_seq, int L, int heads,
+                      int causal, float* out, void* stream);
 int hg_profile_end(hg_ctx*, double* avg_ms, int32_t* launches, double* flops_per_launch, int32_t* mnk);
 
 #ifdef __cplusplus

@@ -1,0 +1,72 @@
+"""Attention kernels (hg_attn.hip) against a plain PyTorch fp32 softmax(QK^T/8)V of the fp16-rounded inputs:
+full attention (ViT L = 197, text L = 77 causal, short / odd / maximum lengths) and the one-row-per-sequence variant
+used by the last block (class token / EOT token), which must reproduce the full kernel's row bit for bit."""
+import pytest
+import torch
+
+from hoigen_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    h = _lib.lib().hg_create(0)
+    assert h
+    yield h
+    _lib.lib().hg_destroy(h)
+
+
+def ref_attention(qkv, n_seq, L, heads, causal):
+    D = heads * 64
+    x = qkv.half().float().view(n_seq, L, 3, heads, 64)
+    q, k, v = (x[:, :, i].permute(0, 2, 1, 3) for i in range(3))          # [n, h, L, 64]
+    s = q @ k.transpose(-1, -2) * 0.125
+    if causal:
+        s = s + torch.full((L, L), float("-inf"), device=s.device).triu(1)
+    return (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(n_seq * L, D)
+
+
+def run_full(ctx, qkv, n_seq, L, heads, causal):
+    out = torch.empty(n_seq * L, heads * 64, device="cuda")
+    rc = _lib.lib().hg_test_attention(ctx, qkv.data_ptr(), None, None, n_seq, L, heads, int(causal), out.data_ptr(), None)
+    assert rc == 0, _lib.lib().hg_last_error(ctx)
+    torch.cuda.synchronize()
+    return out
+
+
+def run_rows(ctx, qkv, q0, sel, n_seq, L, heads, causal):
+    out = torch.empty(n_seq, heads * 64, device="cuda")
+    rc = _lib.lib().hg_test_attention(ctx, qkv.data_ptr(), q0.data_ptr(), sel.data_ptr() if sel is not None else None,
+                                      n_seq, L, heads, int(causal), out.data_ptr(), None)
+    assert rc == 0, _lib.lib().hg_last_error(ctx)
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("n_seq,L,heads,causal", [(9, 197, 12, False), (7, 77, 8, True), (5, 13, 8, True),
+                                                   (3, 1, 2, False), (4, 33, 4, True), (2, 224, 3, False),
+                                                   (3, 224, 2, True), (6, 50, 12, False), (4, 16, 4, True)])
+def test_attention_vs_fp32_reference(ctx, n_seq, L, heads, causal):
+    g = torch.Generator(device="cuda").manual_seed(L * 131 + heads)
+    qkv = torch.randn(n_seq * L, 3 * heads * 64, device="cuda", generator=g) * 1.5
+    want = ref_attention(qkv, n_seq, L, heads, causal)
+    got = run_full(ctx, qkv, n_seq, L, heads, causal)
+    # fp16 probabilities and fp16 output: 2 ulp of fp16 at the top of the range
+    assert (got - want).abs().max().item() <= 2e-3 * want.abs().max().item()
+    assert torch.equal(got, run_full(ctx, qkv, n_seq, L, heads, causal)), "deterministic"
+
+
+@pytest.mark.parametrize("n_seq,L,heads,causal", [(9, 197, 12, False), (7, 77, 8, True), (5, 13, 8, True),
+                                                   (3, 224, 2, True), (4, 33, 4, False)])
+def test_one_row_variant_is_the_full_kernels_row(ctx, n_seq, L, heads, causal):
+    D = heads * 64
+    g = torch.Generator(device="cuda").manual_seed(L * 17 + heads)
+    qkv = torch.randn(n_seq * L, 3 * D, device="cuda", generator=g)
+    full = run_full(ctx, qkv, n_seq, L, heads, causal).view(n_seq, L, D)
+    for sel in (None, torch.randint(0, L, (n_seq,), device="cuda", generator=g, dtype=torch.int32),
+                torch.full((n_seq,), L - 1, device="cuda", dtype=torch.int32)):
+        idx = sel.long() if sel is not None else torch.zeros(n_seq, dtype=torch.long, device="cuda")
+        q0 = qkv.view(n_seq, L, 3 * D)[torch.arange(n_seq, device="cuda"), idx, :D].contiguous()
+        rows = run_rows(ctx, qkv, q0, sel, n_seq, L, heads, causal)
+        assert torch.equal(rows, full[torch.arange(n_seq, device="cuda"), idx]), "same instruction sequence, same bits"
