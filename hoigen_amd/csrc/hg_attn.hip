@@ -124,7 +124,11 @@ __global__ __launch_bounds__(448) void attention_kernel(const half_t* __restrict
         float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
 #pragma unroll
         for (int r = 4; r < 16; r += 4) mx = fmaxf(mx, fmaxf(fmaxf(s[r], s[r + 1]), fmaxf(s[r + 2], s[r + 3])));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        {      // the other half of the query's keys sits in lane ^ 32: v_permlane32_swap (VALU) instead of an LDS round trip
+            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mx), __builtin_bit_cast(unsigned, mx),
+                                                             false, false);
+            mx = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+        }
         if (__any(mx > m)) {                 // some query's running max grew: rescale (wave-uniform branch)
             const float mn = fmaxf(m, mx);
             const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
