@@ -20,7 +20,8 @@ namespace hg {
 static constexpr int BM = 128, BN = 128, BK = 64;
 static constexpr int TILE_BYTES = 128 * BK * 2;          // 16 KiB per operand tile
 static constexpr int STAGE_BYTES = 2 * TILE_BYTES;       // A + W
-static constexpr int GEMM_LDS = 2 * STAGE_BYTES;         // double buffered: 64 KiB
+static constexpr int GEMM_LDS = 2 * STAGE_BYTES;         // double buffered: 64 KiB (two workgroups per CU)
+static constexpr int GEMM_LDS_DEEP = 4 * STAGE_BYTES;    // four stages: 128 KiB, for grids of at most one workgroup per CU
 
 __device__ __forceinline__ float quick_gelu(float v) {
     // x * sigmoid(1.702 x)
@@ -70,7 +71,11 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, int m, int n, f32x4 
     }
 }
 
-template <int EPI>
+// STAGES = 2: tile kt+1 is fetched while tile kt is computed (64 KiB, two workgroups per CU: large grids).
+// STAGES = 4: three tiles in flight behind a counted vmcnt - a small grid (M = 256 rows of the class-token stream, batch
+// 1..16) is bound by the latency of its serial K loop, ~1.1 us per K-tile with one tile in flight.  Same K order:
+// both variants (and the ring kernels) give the same bits.
+template <int EPI, int STAGES>
 __global__ __launch_bounds__(256) void gemm_nt_128x128(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -127,11 +132,21 @@ __global__ __launch_bounds__(256) void gemm_nt_128x128(const GemmArgs p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / BK;
-    stage(0);
+    constexpr int AHEAD = STAGES - 1;                    // tiles in flight
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i)
+        if (i < nk) stage(i);
     for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();   // tile kt landed (vmcnt(0)) and everyone is done with the other buffer
-        if (kt + 1 < nk) stage((kt + 1) & 1);
-        const char* st = smem + (kt & 1) * STAGE_BYTES;
+        // tile kt landed: all but the (8 DMA instructions per wave and tile) x (tiles issued after it) are done
+        const int after = nk - 1 - kt < AHEAD - 1 ? nk - 1 - kt : AHEAD - 1;
+        if (after >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (after == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ... for every wave, and everyone is done with the buffer of tile kt - 1 (its fragments were consumed by
+        // MFMAs already issued).  A raw s_barrier: __syncthreads() would add a full vmcnt(0) drain
+        asm volatile("s_barrier" ::: "memory");
+        if (kt + AHEAD < nk) stage((kt + AHEAD) % STAGES);
+        const char* st = smem + (kt % STAGES) * STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             half8 xf[4], wf[4];
@@ -163,14 +178,25 @@ __global__ __launch_bounds__(256) void gemm_nt_128x128(const GemmArgs p) {
 template <int EPI>
 static hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
     static bool attr_set = false;
+    static int n_cu = 256;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_128x128<EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_128x128<EPI, 2>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_128x128<EPI, 4>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_DEEP);
         if (e != hipSuccess) return e;
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
         attr_set = true;
     }
+    static const bool deep_on = []() { const char* e = getenv("HG_GEMM_DEEP"); return e ? atoi(e) != 0 : true; }();
     const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
-    hipLaunchKernelGGL(gemm_nt_128x128<EPI>, dim3(grid), dim3(256), GEMM_LDS, s, a);
+    if (deep_on && grid <= n_cu && a.K / BK >= 4)
+        hipLaunchKernelGGL((gemm_nt_128x128<EPI, 4>), dim3(grid), dim3(256), GEMM_LDS_DEEP, s, a);
+    else
+        hipLaunchKernelGGL((gemm_nt_128x128<EPI, 2>), dim3(grid), dim3(256), GEMM_LDS, s, a);
     return hipGetLastError();
 }
 
