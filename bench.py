@@ -1,45 +1,90 @@
 #!/usr/bin/env python3
 """Headline benchmark: union-crop embeddings/sec, CLIP ViT-B/16, batch 256 per GPU (BASELINE.json
-configs[1]); weak scaling over N GPUs with one RCCL all-gather of the [256,512] embeddings per step.
+configs[1]); weak scaling over N GPUs (one process per GPU, RCCL all-gather of the [256,512] embeddings per step
+on a side stream = BASELINE.json configs[4] at N = 8).
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]          # N > 1 without WORLD_SIZE: starts the N ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = one pass of ``encode_image`` (hg_encode_image through the façade) over one batch of 256
-synthetic N(0,1) crops already resident in HBM.  Rank 0 prints ONE JSON line.  Weights are the seeded
-synthetic ViT-B/16 of hoigen_amd.synth (no checkpoint is reachable offline).
+A step = one pass of ``encode_image`` over one batch of 256 synthetic N(0,1) crops already resident in HBM.
+Rank 0 prints ONE JSON line.  Weights are the seeded synthetic ViT-B/16 of hoigen_amd.synth (no checkpoint is
+reachable offline).  `value` is measured with every row of every block computed (HG_LAST_BLOCK_ROW0=0).
 
 Extra objects on the line:
-  roofline      dominant kernel (the c_fc GEMM: M=50432, N=3072, K=768) timed live with hipEvent pairs on
-                its own stream during the timed region; achieved = 2*M*N*K / mean duration vs the dense
-                16-bit MFMA peak 2516.6 TFLOP/s.  `e2e_frac` = whole-step algorithmic FLOPs / step time.
-  cpu_baseline  the CPU oracle (oracle/clip_oracle.py, a port of the reference's CPU path pinned to the
-                reference's own outputs) timed on this box's host cores on a bounded sample (rank 0, N=1).
+  roofline         the kernel with the largest share of the step (found by timing every GEMM / attention launch of
+                   two untimed steps), timed live with hipEvent pairs on its launch stream during the first timed
+                   steps: achieved = mean algorithmic FLOPs per launch / mean duration, vs the dense 16-bit MFMA peak
+                   2516.6 TFLOP/s.  `e2e_frac` = whole-step algorithmic FLOPs / step time: THE figure to hold against
+                   the 40 % target.
+  kernels          per launch shape: launches per step, mean ms, FLOPs, fraction of MFMA peak, algorithmic HBM bytes
+                   and fraction of 8 TB/s (from the two untimed, fully instrumented steps).
+  step_ms          median / p10 / p90 of the individual timed steps (events on the compute stream).
+  class_rows_only  the library's default (last block on the class-token rows only), same protocol.
+  config3/config4  (N = 1) encode_text over the 600 HICO prompts and the CoOp-VAE on 100 000 rows, each with its own
+                   CPU baseline sample.
+  cpu_baseline     the CPU oracle (a port of the reference's CPU path, pinned to the reference's own outputs) timed on
+                   this box's host cores on a bounded sample (rank 0, N = 1).
 """
 import argparse
-import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
 
 MFMA_PEAK_TFLOPS = 2516.6          # 256 CU x 4096 FLOP/clk/CU x 2.4 GHz (dense fp16/bf16), BASELINE.md §2
+HBM_PEAK_GBS = 8000.0
 FLOPS_PER_CROP = 35.127e9          # BASELINE.md §2 (every row of every block)
 # The library's default runs the LAST block's attention, out-proj and MLP on the class-token row only (its other 196
-# rows never reach the embedding).  The headline `value` is measured with HG_LAST_BLOCK_ROW0=0, i.e. with every row
-# of every block computed like the reference does; the default path is timed right after it and reported in the
-# extra object `class_rows_only` with the FLOPs it really executes (per skipped row: the Q and out projections,
-# c_fc + c_proj, and its attention row over 197 keys).
+# rows never reach the embedding); per skipped row: the Q and out projections, c_fc + c_proj, its attention row.
 FLOPS_DEAD_ROWS = 196 * (2 * 2 * 768 * 768 + 2 * 2 * 768 * 3072 + 4 * 197 * 768)
 BATCH = 256
-GEMM_CLASS_FC = 1                  # EPI_BIAS_QGELU_F16: the c_fc GEMM (M=B*197, N=3072, K=768)
+KIND_NAMES = {0: "gemm bias->f16", 1: "gemm bias+QuickGELU->f16", 2: "gemm bias+ReLU->f16", 3: "gemm bias+residual",
+              4: "gemm bias->f32", 5: "gemm patch-embed", 6: "gemm bias+ReLU->f32", 7: "gemm scale+residual",
+              8: "gemm_ring<LN-fold bias->f16>", 9: "gemm_ring<LN-fold bias+QuickGELU->f16>",
+              10: "gemm_ring2<residual + x16 + row stats>", 11: "vae_fused", 100: "attention_kernel"}
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=BATCH, help="crops per GPU per step (metric is quoted at 256)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the config3 / config4 objects")
+    return ap.parse_args()
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (one per GPU, like the
+    reference's mp.spawn, main_tip_finetune.py:1205-1208).  Nothing in this process has touched the GPU runtime, and
+    it never replaces itself: it relays rank 0's JSON line and the children's exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--batch", str(args.batch)]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    if args.no_extra_configs:
+        cmd.append("--no-extra-configs")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for line in proc.stdout:
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+        sys.stdout.flush()
+    return proc.wait()
 
 
 def host_cores() -> int:
@@ -54,7 +99,9 @@ def host_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(budget_s: float = 20.0):
+# ---- CPU baselines (the oracle is the checker / baseline only; never on the timed path) ---------------------------
+def cpu_baseline(budget_s: float = 16.0):
+    import torch
     from hoigen_amd import synth
     from oracle import clip_oracle as co
 
@@ -78,23 +125,162 @@ def cpu_baseline(budget_s: float = 20.0):
                       f"{n * FLOPS_PER_CROP / t_tot / 1e9:.0f} GFLOP/s)"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=BATCH, help="crops per GPU per step (metric is quoted at 256)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def text_flops(L: int, width: int = 512, layers: int = 12, last_block_one_row: bool = False) -> float:
+    """Algorithmic FLOPs of the text tower for one prompt of L tokens (5.960 GFLOP at L = 77)."""
+    blk = 2 * L * width * 3 * width + 4 * L * L * width + 2 * L * width * width + 4 * L * width * 4 * width
+    if not last_block_one_row:
+        return layers * blk + 2 * width * width
+    last = 2 * L * width * 2 * width + 2 * width * width + 4 * L * width + 2 * width * width + 4 * width * 4 * width
+    return (layers - 1) * blk + last + 2 * width * width
+
+
+def timed(fn, iters: int, warm: int = 2) -> float:
+    """Median milliseconds of fn() over `iters` runs (events on the current stream)."""
+    import torch
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        b.synchronize()
+        ts.append(a.elapsed_time(b))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def config3(model, dev, with_cpu: bool):
+    """BASELINE config 3: encode_text over the 600 HICO HOI prompts (fixture G0 token ids), 77 tokens."""
+    import numpy as np
+    import torch
+    g0 = json.load(open(os.path.join(HERE, "tests", "golden", "g0_tokens.json")))
+    rows = g0["hoi600"]["ids"]
+    ids = np.zeros((len(rows), 77), np.int64)
+    for i, r in enumerate(rows):
+        ids[i, :len(r)] = r
+    ids_d = torch.from_numpy(ids).to(dev)
+    T = ids.shape[0]
+    Lt = int(ids.argmax(-1).max()) + 1
+    out = {"workload": f"encode_text, {T} HICO HOI prompts x 77 tokens (hico_text_label.py; BASELINE.json configs[2])"}
+    for name, trunc in (("full_77_tokens", False), ("truncated", True)):
+        model.truncate_text = trunc
+        ms = timed(lambda: model.encode_text(ids_d), 10)
+        L = Lt if trunc else 77
+        nominal, executed = T * text_flops(77), T * text_flops(L, last_block_one_row=True)
+        out[name] = {"ms": round(ms, 4), "prompts_per_s": round(T / ms * 1e3, 1), "tokens_run": L,
+                     "nominal_tflops": round(nominal / ms / 1e9, 2),
+                     "frac_nominal": round(nominal / ms / 1e9 / MFMA_PEAK_TFLOPS, 4),
+                     "executed_tflops": round(executed / ms / 1e9, 2),
+                     "frac_executed": round(executed / ms / 1e9 / MFMA_PEAK_TFLOPS, 4)}
+    model.truncate_text = True
+    if with_cpu:
+        from hoigen_amd import synth
+        from oracle import clip_oracle as co
+        sd = co.reference_weight_rounding(synth.clip_state_dict(synth.VIT_B16, 0))
+        sample = torch.from_numpy(ids[:64])
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            co.encode_text(sd, sample)
+            dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(64 / dt, 2), "unit": "prompts/s", "cores": torch.get_num_threads(),
+                               "kind": "port", "sample": "first 64 prompts x 77 tokens, oracle/clip_oracle.py encode_text"}
+    return out
+
+
+def config4(dev, with_cpu: bool):
+    """BASELINE config 4: CoOp-VAE (Encoder -> reparameterise -> Generator) on 100 000 rows x 512."""
+    import torch
+    from hoigen_amd import _lib, synth, vae
+    R = 100_000
+    se, sg = synth.encoder_state_dict(2), synth.generator_state_dict(3)
+    E, G = vae.Encoder().to(dev), vae.Generator().to(dev)
+    E.load_state_dict(synth.to_torch(se))
+    G.load_state_dict(synth.to_torch(sg))
+    V = vae.VAE(E, G)
+    gen = torch.Generator(device=dev).manual_seed(44)
+    x = vae.l2_normalize(torch.randn(R, 512, device=dev, generator=gen))
+    eps = torch.randn(R, 512, device=dev, generator=gen)
+    z = torch.randn(R, 512, device=dev, generator=gen)
+    ms_full = timed(lambda: V(x, eps), 10)
+    ms_gen = timed(lambda: G(z), 10)
+    _, recs = _lib.profile(V._ctx.handle, _lib.HG_PROF_ALL, 64, lambda: V(x, eps))
+    out = {"workload": f"CoOp-VAE Encoder->reparameterise->Generator, {R} rows x 512 (BASELINE.json configs[3]); "
+                       "inputs and the four outputs (mean, log_var, z, bias) fp32 in HBM",
+           "ms": round(ms_full, 4), "rows_per_s": round(R / ms_full * 1e3, 0),
+           "tflops": round(R * 14.680e6 / ms_full / 1e9, 2),
+           "frac": round(R * 14.680e6 / ms_full / 1e9 / MFMA_PEAK_TFLOPS, 4),
+           "generator_only": {"ms": round(ms_gen, 4), "tflops": round(R * 8.389e6 / ms_gen / 1e9, 2),
+                              "frac": round(R * 8.389e6 / ms_gen / 1e9 / MFMA_PEAK_TFLOPS, 4)},
+           "launches_per_call": len(recs),
+           "kernels": [{"kind": KIND_NAMES.get(k, str(k)), "M": m, "N": n, "K": kk, "ms": round(t, 4)}
+                       for k, m, n, kk, t in recs]}
+    if with_cpu:
+        from oracle import clip_oracle as co, vae_oracle as vo
+        n = 8192
+        xs, es = x[:n].cpu(), eps[:n].cpu()
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            vo.vae_forward(co.as_tensors(se), co.as_tensors(sg), xs, es)
+            dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(n / dt, 1), "unit": "rows/s", "cores": torch.get_num_threads(),
+                               "kind": "port", "sample": f"{n} rows, oracle/vae_oracle.py vae_forward (fp32)"}
+    return out
+
+
+# ---- per-kernel accounting ---------------------------------------------------------------------------------------
+def kernel_row(kind, M, N, K):
+    """(name, algorithmic FLOPs, algorithmic HBM bytes) of one launch."""
+    if kind == 100:                       # attention: M sequences of N tokens, K heads of 64
+        rows, D = M * N, K * 64
+        return f"attention (L={N}, {K} heads)", 4.0 * M * K * N * N * 64, rows * 3 * D * 2 + rows * D * 2
+    fl = 2.0 * M * N * K
+    w = N * K * 2
+    if kind in (0, 8):
+        return f"in_proj / QKV (N={N}, K={K})", fl, M * K * 2 + w + M * N * 2
+    if kind in (1, 9):
+        return f"c_fc + QuickGELU (N={N}, K={K})", fl, M * K * 2 + w + M * N * 2
+    if kind in (3, 10):
+        extra = M * N * 2 if kind == 10 else 0       # fp16 copy for the next LayerNorm-folded GEMM
+        nm = "out_proj" if K == N else "c_proj"
+        return f"{nm} + residual (N={N}, K={K})", fl, M * K * 2 + w + 2 * M * N * 4 + extra
+    if kind == 5:
+        return f"patch embedding (K={K})", fl, M * K * 2 + w + M * N * 4
+    return f"{KIND_NAMES.get(kind, kind)} (M={M}, N={N}, K={K})", fl, M * K * 2 + w + M * N * 4
+
+
+def aggregate(recs, steps):
+    rows = {}
+    for kind, M, N, K, ms in recs:
+        name, fl, by = kernel_row(kind, M, N, K)
+        r = rows.setdefault((kind, M, N, K), {"name": name, "kernel": KIND_NAMES.get(kind, str(kind)), "kind": kind,
+                                              "n": 0, "ms": 0.0, "flops": fl, "hbm_bytes": by})
+        r["n"] += 1
+        r["ms"] += ms
+    out = []
+    for r in rows.values():
+        avg = r["ms"] / r["n"]
+        out.append({"name": r["name"], "kernel": r["kernel"], "kind": r["kind"], "launches_per_step": r["n"] / steps,
+                    "avg_ms": round(avg, 4), "ms_per_step": round(r["ms"] / steps, 4),
+                    "gflop": round(r["flops"] / 1e9, 2), "tflops": round(r["flops"] / avg / 1e9, 1),
+                    "frac": round(r["flops"] / avg / 1e9 / MFMA_PEAK_TFLOPS, 4),
+                    "hbm_bytes": int(r["hbm_bytes"]), "hbm_gbs": round(r["hbm_bytes"] / avg / 1e6, 0),
+                    "hbm_frac": round(r["hbm_bytes"] / avg / 1e6 / HBM_PEAK_GBS, 4)})
+    out.sort(key=lambda r: -r["ms_per_step"])
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def run(args):
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -102,57 +288,75 @@ def main():
         dist.init_process_group("nccl", device_id=dev)   # RCCL
 
     from hoigen_amd import _lib, synth
+    from hoigen_amd.distributed import ShardedEncoder
     from hoigen_amd.model import build_model
 
     model = build_model(synth.to_torch(synth.clip_state_dict(synth.VIT_B16, 0))).to(dev)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     crops = torch.randn(args.batch, 3, 224, 224, device=dev, generator=gen)     # resident in HBM
-    gathered = torch.empty(world * args.batch, 512, device=dev, dtype=torch.float32) if world > 1 else None
+    sharded = ShardedEncoder(model.visual.encode_into, args.batch, 512, dev) if world > 1 else None
 
     def step():
-        emb = model.visual(crops)                        # [B,512] in model.dtype (fp16, like the reference on GPU)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, emb.float())
-            return gathered
-        return emb
+        if sharded is not None:
+            return sharded.step(crops)[0]                # encode into this rank's slice + all-gather on the side stream
+        return model.visual(crops)                       # [B,512] in model.dtype (fp16, like the reference on GPU)
 
     def fence():
+        if sharded is not None:
+            sharded.finish()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    def timed_region(profile_kind=None, profile_steps=0, launches_per_step=0):
+        """Exactly args.steps steps between two fences -> (seconds, per-step ms list, live kernel records, last out)."""
+        h = model.visual._ctx.handle
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        recs = []
+        fence()
+        if profile_kind is not None:
+            _lib.lib().hg_profile_begin(h, profile_kind, profile_steps * launches_per_step)
+        t0 = time.perf_counter()
+        ev[0].record()
+        for i in range(args.steps):
+            out = step()
+            ev[i + 1].record()
+        fence()
+        dt = time.perf_counter() - t0
+        if profile_kind is not None:
+            import ctypes as C
+            buf = (_lib.hg_prof_rec * max(1, profile_steps * launches_per_step))()
+            n = C.c_int32()
+            _lib.lib().hg_profile_end(h, buf, profile_steps * launches_per_step, C.byref(n))
+            recs = [(r.kind, r.M, r.N, r.K, float(r.ms)) for r in buf[: n.value]]
+        per_step = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
+        return dt, per_step, recs, out
+
     os.environ["HG_LAST_BLOCK_ROW0"] = "0"       # headline: every row of every block (read per call by the library)
     for _ in range(args.warmup):
         step()
-    h = model.visual._ctx.handle
-    lib = _lib.lib()
-    n_layers = model.visual.transformer.layers
-    # hipEvent pairs around every c_fc launch of the first (up to) 4 timed steps: an event record costs ~5 us on the
-    # stream, so timing all launches would inflate ms_per_step by ~1 %
-    lib.hg_profile_begin(h, GEMM_CLASS_FC, min(args.steps, 4) * n_layers)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    dt = time.perf_counter() - t0
-    avg_ms, launches, flops = C.c_double(), C.c_int32(), C.c_double()
-    mnk = (C.c_int32 * 3)()
-    lib.hg_profile_end(h, C.byref(avg_ms), C.byref(launches), C.byref(flops), mnk)
+    # two more untimed steps with every GEMM / attention launch bracketed by events: the per-kernel table, and which
+    # kernel the live `roofline` measurement of the timed region follows
+    PROF_STEPS = 2
+    _, all_recs = _lib.profile(model.visual._ctx.handle, _lib.HG_PROF_ALL, PROF_STEPS * 128,
+                               lambda: [step() for _ in range(PROF_STEPS)])
+    kernels = aggregate(all_recs, PROF_STEPS)
+    by_kind = {}
+    for k in kernels:
+        by_kind[k["kind"]] = by_kind.get(k["kind"], 0.0) + k["ms_per_step"]
+    dom_kind = max(by_kind, key=by_kind.get)
+    dom_launches = int(round(sum(k["launches_per_step"] for k in kernels if k["kind"] == dom_kind)))
+
+    dt, per_step, live, out = timed_region(dom_kind, min(args.steps, 4), dom_launches)
     assert torch.isfinite(out).all()
-    out = out.clone()                                    # (`gathered` is reused by the next steps)
+    out = out.clone()                                    # (the gather buffers are reused by the next steps)
 
     # the library's default path (last block on the class-token rows only), same protocol
     os.environ["HG_LAST_BLOCK_ROW0"] = "1"
     for _ in range(args.warmup):
         step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out2 = step()
-    fence()
-    dt2 = time.perf_counter() - t0
+    dt2, per_step2, _, out2 = timed_region()
     assert torch.isfinite(out2).all()
     rel = float(((out2.float() - out.float()).norm() / out.float().norm()).item())
 
@@ -162,17 +366,23 @@ def main():
     dt, dt2 = float(t[0].item()), float(t[1].item())
 
     if rank == 0:
-        flops_per_crop = FLOPS_PER_CROP
         ms_per_step = dt / args.steps * 1e3
         value = world * args.batch * args.steps / dt
-        ach = flops.value / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0
+        flops_l = sum(kernel_row(*r[:4])[1] for r in live) / max(1, len(live))
+        bytes_l = sum(kernel_row(*r[:4])[2] for r in live) / max(1, len(live))
+        ms_l = sum(r[4] for r in live) / max(1, len(live))
+        ach = flops_l / ms_l / 1e9 if ms_l > 0 else 0.0
         traffic = None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
+        tpath = os.path.join(HERE, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("c_fc_gemm_hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get(f"kind{dom_kind}_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        ps = sorted(per_step)
+        pct = lambda q: round(ps[min(len(ps) - 1, int(q * len(ps)))], 4)
+        e2e = value / world * FLOPS_PER_CROP / 1e12
+        shapes = sorted({(r[1], r[2], r[3]) for r in live})
         line = {
             "metric": "union-crop embeddings/sec ViT-B/16 bs=256",
             "value": round(value, 2), "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -180,17 +390,25 @@ def main():
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": "CLIP ViT-B/16 union-region encode (encode_image), 224x224 crops, "
                                    f"batch {args.batch} per GPU, synthetic N(0,1) crops + seeded synthetic weights "
-                                   "(BASELINE.json configs[1])",
+                                   "(BASELINE.json configs[1]" + ("; configs[4] at 8 GPUs: 2048 crops per step" if world > 1 else "") + ")",
                        "last_block": "all rows (HG_LAST_BLOCK_ROW0=0)",
-                       "flops_per_crop_executed": round(flops_per_crop / 1e9, 3),
+                       "flops_per_crop_executed": round(FLOPS_PER_CROP / 1e9, 3),
                        "batch_per_gpu": args.batch, "global_batch": world * args.batch,
-                       "parallelism": f"dp{world}" + (" + all_gather[256x512 f32]/step" if world > 1 else "")},
-            "roofline": {"bound": "mfma", "kernel": f"gemm_ring (c_fc: M={mnk[0]} N={mnk[1]} K={mnk[2]}, LayerNorm-folded bias+QuickGELU->f16)",
+                       "parallelism": f"dp{world}" + (f" + in-place all_gather[{world}x{args.batch}x512 f32] per step on a side stream" if world > 1 else "")},
+            "step_ms": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "how": "hipEvents on the compute stream around every timed step"},
+            "roofline": {"bound": "mfma",
+                         "kernel": f"{KIND_NAMES.get(dom_kind, dom_kind)}: the kernel with the largest share of the step "
+                                   f"({by_kind[dom_kind]:.3f} of {sum(by_kind.values()):.3f} ms of GEMM+attention time), "
+                                   f"{dom_launches} launches per step, shapes (M,N,K) {shapes}",
                          "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "avg_kernel_ms": round(avg_ms.value, 4), "launches_timed": launches.value,
-                         "e2e_tflops": round(value / world * flops_per_crop / 1e12, 2),
-                         "e2e_frac": round(value / world * flops_per_crop / 1e12 / MFMA_PEAK_TFLOPS, 4)},
+                         "avg_kernel_ms": round(ms_l, 4), "avg_gflop_per_launch": round(flops_l / 1e9, 2),
+                         "launches_timed": len(live),
+                         "algorithmic_hbm_bytes_per_launch": int(bytes_l),
+                         "hbm_frac_algorithmic": round(bytes_l / ms_l / 1e6 / HBM_PEAK_GBS, 4) if ms_l > 0 else None,
+                         "e2e_tflops": round(e2e, 2), "e2e_frac": round(e2e / MFMA_PEAK_TFLOPS, 4),
+                         "target_e2e_frac": 0.40},
+            "kernels": [{k: v for k, v in r.items() if k != "kind"} for r in kernels],
         }
         v2 = world * args.batch * args.steps / dt2
         f2 = FLOPS_PER_CROP - FLOPS_DEAD_ROWS
@@ -201,12 +419,29 @@ def main():
             "flops_per_crop_executed": round(f2 / 1e9, 3),
             "e2e_frac": round(v2 / world * f2 / 1e12 / MFMA_PEAK_TFLOPS, 4),
             "rel_l2_vs_all_rows": float(f"{rel:.3e}")}
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+        if world == 1:
+            with_cpu = not args.no_cpu_baseline
+            if with_cpu:
+                line["cpu_baseline"] = cpu_baseline()
+            if not args.no_extra_configs:
+                line["config3"] = config3(model, dev, with_cpu)
+                line["config4"] = config4(dev, with_cpu)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None:
+        if args.gpus > 1:                     # decided from argv / env alone, before anything touches the GPU runtime
+            sys.exit(self_launch(args))
+    elif int(world_env) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world_env}; start it with "
+                         f"--nproc-per-node {args.gpus} (or without a launcher: bench.py starts the ranks itself)")
+    run(args)
 
 
 if __name__ == "__main__":

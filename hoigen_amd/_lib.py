@@ -83,6 +83,12 @@ class hg_cache_weights(C.Structure):
                 ("S", C.c_int32), ("K", C.c_int32), ("C", C.c_int32), ("post_div", C.c_float)]
 
 
+class hg_prof_rec(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("ms", C.c_float)]
+
+
+HG_PROF_OFF, HG_PROF_ALL, HG_PROF_ATTENTION, HG_PROF_VAE = -1, -2, 100, 11
+
 _P = C.c_void_p
 _I = C.c_int
 # name -> (restype, argtypes); must list every symbol of include/hoigen_amd.h (tests check this)
@@ -116,8 +122,7 @@ SIGNATURES = {
     "hg_test_gemm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "hg_test_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "hg_profile_begin": (_I, [_P, _I, _I]),
-    "hg_profile_end": (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_double),
-                            C.POINTER(C.c_int32)]),
+    "hg_profile_end": (_I, [_P, _P, _I, C.POINTER(C.c_int32)]),
 }
 
 _lib = None
@@ -179,6 +184,24 @@ def check(device: int, rc: int, what: str) -> None:
     if rc != 0:
         msg = lib().hg_last_error(ctx(device))
         raise RuntimeError(f"hoigen_amd: {what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def profile(handle: int, kind: int, max_launches: int, fn):
+    """Run ``fn()`` with hipEvent pairs around the launches of ``kind`` (HG_PROF_ALL: every GEMM / attention /
+    fused-VAE launch) of the context ``handle``; returns ``(fn's result, [(kind, M, N, K, ms), ...])``."""
+    l = lib()
+    rc = l.hg_profile_begin(handle, kind, max_launches)
+    if rc:
+        raise RuntimeError(f"hoigen_amd: hg_profile_begin failed ({rc})")
+    try:
+        out = fn()
+    finally:
+        recs = (hg_prof_rec * max(1, max_launches))()
+        n = C.c_int32()
+        rc = l.hg_profile_end(handle, recs, max_launches, C.byref(n))
+    if rc:
+        raise RuntimeError(f"hoigen_amd: hg_profile_end failed ({rc})")
+    return out, [(r.kind, r.M, r.N, r.K, float(r.ms)) for r in recs[: n.value]]
 
 
 def tensor(t: Optional["object"]) -> hg_tensor:

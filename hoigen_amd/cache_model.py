@@ -7,7 +7,6 @@ Counterpart of the expressions in upt_tip_cache_model_free_finetune_distill3.py:
 as two MFMA GEMMs behind ``hg_load_cache`` / ``hg_cache_logits``.  Inference only; CPU tensors raise
 ``RuntimeError`` (there is no CPU fallback).
 """
-import itertools
 import threading
 from typing import Optional
 
@@ -15,7 +14,8 @@ import torch
 
 from . import _lib
 
-_slots = itertools.cycle(range(8))          # HG_MAX_CACHE_SLOTS
+HG_MAX_CACHE_SLOTS = 8                      # include/hoigen_amd.h
+_free = list(range(HG_MAX_CACHE_SLOTS))     # slots of the shared per-device context not owned by a live object
 _lock = threading.Lock()
 
 
@@ -36,11 +36,34 @@ class CacheLogits:
     def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None,
                  sample_lens: Optional[torch.Tensor] = None, post_div: float = 1.0):
         with _lock:
-            self.slot = next(_slots)
+            if not _free:
+                raise RuntimeError(f"hoigen_amd: all {HG_MAX_CACHE_SLOTS} cache-model slots are in use; close() or "
+                                   "delete a CacheLogits first")
+            self.slot = _free.pop(0)
         self.post_div = float(post_div)
-        self.update(weight, bias, labels, sample_lens)
+        try:
+            self.update(weight, bias, labels, sample_lens)
+        except Exception:
+            self.close()
+            raise
+
+    def close(self):
+        """Give the slot back (the object is unusable afterwards)."""
+        with _lock:
+            if getattr(self, "slot", None) is not None:
+                _free.append(self.slot)
+                _free.sort()
+                self.slot = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover - interpreter shutdown
+            pass
 
     def update(self, weight, bias=None, labels=None, sample_lens=None):
+        if self.slot is None:
+            raise RuntimeError("hoigen_amd: this CacheLogits has been closed")
         self.device = _dev_index(weight)
         if (labels is None) != (sample_lens is None):
             raise ValueError("labels and sample_lens go together")
@@ -56,6 +79,8 @@ class CacheLogits:
         _lib.check(self.device, rc, "hg_load_cache")
 
     def __call__(self, features: torch.Tensor) -> torch.Tensor:
+        if self.slot is None:
+            raise RuntimeError("hoigen_amd: this CacheLogits has been closed")
         if _dev_index(features) != self.device:
             raise RuntimeError("features are on a different device than the cache model")
         if features.dim() != 2 or features.shape[1] != self.K:

@@ -110,13 +110,12 @@ struct hg_ctx {
     int max_chunk_img = 256;
     int max_chunk_txt = 640;
     int max_chunk_rows = 32768;
-    // live per-kernel timing for bench.py (hg_profile_begin/end): hipEvent pairs around every launch
-    // of one GEMM epilogue class, on the stream the kernel is launched on
-    int prof_class = -1;
+    // live per-kernel timing for bench.py (hg_profile_begin/end): hipEvent pairs around the launches of one kernel
+    // kind (or of every GEMM and attention launch), on the stream the kernel is launched on
+    int prof_kind = HG_PROF_OFF;
     std::vector<hipEvent_t> prof_ev;
+    std::vector<hg_prof_rec> prof_rec;
     size_t prof_n = 0;
-    double prof_flops = 0.0;
-    int prof_M = 0, prof_N = 0, prof_K = 0;
 };
 
 namespace {
@@ -139,6 +138,29 @@ int fail(hg_ctx* c, int code, const char* fmt, ...) {
                         __LINE__);                                                                     \
     } while (0)
 
+// Entry points run on the context's device and give the caller's current device back on return (torch tracks the
+// current device per thread; a library that silently changes it redirects the caller's next allocation).
+struct DevGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DevGuard(const hg_ctx* c) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != c->device) err = hipSetDevice(c->device);
+        else prev = -1;
+    }
+    ~DevGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+#define HG_ON_DEVICE(c)                                                                                 \
+    DevGuard dev_guard_(c);                                                                             \
+    if (dev_guard_.err != hipSuccess)                                                                   \
+        return fail(c, HG_ERR_HIP, "hipSetDevice(%d) failed: %s", (c)->device, hipGetErrorString(dev_guard_.err))
+// first failing status wins (OR-ing negative codes can turn OOM into another code)
+inline void keep_first(int& rc, int r) {
+    if (!rc) rc = r;
+}
+
 int ensure(hg_ctx* c, Buf& b, size_t bytes) {
     if (b.bytes >= bytes) return HG_OK;
     if (b.p) HG_HIP(hipFree(b.p));
@@ -147,7 +169,10 @@ int ensure(hg_ctx* c, Buf& b, size_t bytes) {
     bytes = (bytes + 255) & ~(size_t)255;
     hipError_t e = hipMalloc(&b.p, bytes);
     if (e != hipSuccess) return fail(c, HG_ERR_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    // growth only (never in steady state): zero the padding rows and order the memset against every stream, also
+    // non-blocking ones that do not synchronise with the null stream
     HG_HIP(hipMemset(b.p, 0, bytes));
+    HG_HIP(hipDeviceSynchronize());
     b.bytes = bytes;
     return HG_OK;
 }
@@ -232,26 +257,26 @@ int load_blocks(hg_ctx* c, std::vector<void*>& owned, const hg_block_weights* sr
         const hg_block_weights& s = src[i];
         BlockW& b = dst[i];
         int rc = 0;
-        rc |= as_f16(c, owned, s.in_proj_weight, (size_t)3 * D * D, &b.w_qkv, "attn.in_proj_weight");
-        rc |= as_f32(c, owned, s.in_proj_bias, (size_t)3 * D, &b.b_qkv, "attn.in_proj_bias");
-        rc |= as_f16(c, owned, s.out_proj_weight, (size_t)D * D, &b.w_out, "attn.out_proj.weight");
-        rc |= as_f32(c, owned, s.out_proj_bias, D, &b.b_out, "attn.out_proj.bias");
-        rc |= as_f32(c, owned, s.ln_1_weight, D, &b.ln1_w, "ln_1.weight");
-        rc |= as_f32(c, owned, s.ln_1_bias, D, &b.ln1_b, "ln_1.bias");
-        rc |= as_f16(c, owned, s.c_fc_weight, (size_t)4 * D * D, &b.w_fc, "mlp.c_fc.weight");
-        rc |= as_f32(c, owned, s.c_fc_bias, (size_t)4 * D, &b.b_fc, "mlp.c_fc.bias");
-        rc |= as_f16(c, owned, s.c_proj_weight, (size_t)4 * D * D, &b.w_proj, "mlp.c_proj.weight");
-        rc |= as_f32(c, owned, s.c_proj_bias, D, &b.b_proj, "mlp.c_proj.bias");
-        rc |= as_f32(c, owned, s.ln_2_weight, D, &b.ln2_w, "ln_2.weight");
-        rc |= as_f32(c, owned, s.ln_2_bias, D, &b.ln2_b, "ln_2.bias");
+        keep_first(rc, as_f16(c, owned, s.in_proj_weight, (size_t)3 * D * D, &b.w_qkv, "attn.in_proj_weight"));
+        keep_first(rc, as_f32(c, owned, s.in_proj_bias, (size_t)3 * D, &b.b_qkv, "attn.in_proj_bias"));
+        keep_first(rc, as_f16(c, owned, s.out_proj_weight, (size_t)D * D, &b.w_out, "attn.out_proj.weight"));
+        keep_first(rc, as_f32(c, owned, s.out_proj_bias, D, &b.b_out, "attn.out_proj.bias"));
+        keep_first(rc, as_f32(c, owned, s.ln_1_weight, D, &b.ln1_w, "ln_1.weight"));
+        keep_first(rc, as_f32(c, owned, s.ln_1_bias, D, &b.ln1_b, "ln_1.bias"));
+        keep_first(rc, as_f16(c, owned, s.c_fc_weight, (size_t)4 * D * D, &b.w_fc, "mlp.c_fc.weight"));
+        keep_first(rc, as_f32(c, owned, s.c_fc_bias, (size_t)4 * D, &b.b_fc, "mlp.c_fc.bias"));
+        keep_first(rc, as_f16(c, owned, s.c_proj_weight, (size_t)4 * D * D, &b.w_proj, "mlp.c_proj.weight"));
+        keep_first(rc, as_f32(c, owned, s.c_proj_bias, D, &b.b_proj, "mlp.c_proj.bias"));
+        keep_first(rc, as_f32(c, owned, s.ln_2_weight, D, &b.ln2_w, "ln_2.weight"));
+        keep_first(rc, as_f32(c, owned, s.ln_2_bias, D, &b.ln2_b, "ln_2.bias"));
         if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
         if (!fold_ln) continue;
-        rc |= dev_alloc(c, owned, (size_t)3 * D * D * 2, (void**)&b.wf_qkv);
-        rc |= dev_alloc(c, owned, (size_t)3 * D * 4, (void**)&b.cs_qkv);
-        rc |= dev_alloc(c, owned, (size_t)3 * D * 4, (void**)&b.bf_qkv);
-        rc |= dev_alloc(c, owned, (size_t)4 * D * D * 2, (void**)&b.wf_fc);
-        rc |= dev_alloc(c, owned, (size_t)4 * D * 4, (void**)&b.cs_fc);
-        rc |= dev_alloc(c, owned, (size_t)4 * D * 4, (void**)&b.bf_fc);
+        keep_first(rc, dev_alloc(c, owned, (size_t)3 * D * D * 2, (void**)&b.wf_qkv));
+        keep_first(rc, dev_alloc(c, owned, (size_t)3 * D * 4, (void**)&b.cs_qkv));
+        keep_first(rc, dev_alloc(c, owned, (size_t)3 * D * 4, (void**)&b.bf_qkv));
+        keep_first(rc, dev_alloc(c, owned, (size_t)4 * D * D * 2, (void**)&b.wf_fc));
+        keep_first(rc, dev_alloc(c, owned, (size_t)4 * D * 4, (void**)&b.cs_fc));
+        keep_first(rc, dev_alloc(c, owned, (size_t)4 * D * 4, (void**)&b.bf_fc));
         if (rc) return rc < 0 ? rc : HG_ERR_OOM;
         HG_HIP(launch_fold_ln(b.w_qkv, b.ln1_w, b.ln1_b, b.b_qkv, b.wf_qkv, b.cs_qkv, b.bf_qkv, 3 * D, D, 0));
         HG_HIP(launch_fold_ln(b.w_fc, b.ln2_w, b.ln2_b, b.b_fc, b.wf_fc, b.cs_fc, b.bf_fc, 4 * D, D, 0));
@@ -276,8 +301,8 @@ int load_decoder_layer(hg_ctx* c, std::vector<void*>& owned, const hg_decoder_la
     }
     free_all(scratch);
     if (rc) return rc;
-    rc |= as_f32_T(c, owned, s.attn_out_proj_weight, d, d, &dl[6], "adapter out_proj.weight");
-    rc |= as_f32(c, owned, s.attn_out_proj_bias, d, &dl[7], "adapter out_proj.bias");
+    keep_first(rc, as_f32_T(c, owned, s.attn_out_proj_weight, d, d, &dl[6], "adapter out_proj.weight"));
+    keep_first(rc, as_f32(c, owned, s.attn_out_proj_bias, d, &dl[7], "adapter out_proj.bias"));
     // norm2 | norm3 packed: [w2, b2, w3, b3] (4*d)
     {
         float* p;
@@ -295,8 +320,8 @@ int load_decoder_layer(hg_ctx* c, std::vector<void*>& owned, const hg_decoder_la
         }
         dl[8] = p;
     }
-    rc |= as_f32_T(c, owned, s.linear1_weight, 2 * d, d, &dl[9], "adapter linear1.weight");   // [d, 2d]
-    rc |= as_f32(c, owned, s.linear1_bias, (size_t)2 * d, &dl[10], "adapter linear1.bias");
+    keep_first(rc, as_f32_T(c, owned, s.linear1_weight, 2 * d, d, &dl[9], "adapter linear1.weight"));   // [d, 2d]
+    keep_first(rc, as_f32(c, owned, s.linear1_bias, (size_t)2 * d, &dl[10], "adapter linear1.bias"));
     // linear2: weight^T [2d, d] followed by bias [d]
     {
         float* w2t;
@@ -355,9 +380,9 @@ int load_adapters(hg_ctx* c, const hg_adapter_weights* src, int layers) {
             free_all(sc);
             if (rc) return rc;
         }
-        rc |= as_f16(c, own, s.up_proj_weight, (size_t)D * d, &a.up_w, "adapter up_proj.weight");
-        rc |= as_f32(c, own, s.up_proj_bias, D, &a.up_b, "adapter up_proj.bias");
-        rc |= as_f32(c, own, s.scale, D, &a.scale, "adapter scale");
+        keep_first(rc, as_f16(c, own, s.up_proj_weight, (size_t)D * d, &a.up_w, "adapter up_proj.weight"));
+        keep_first(rc, as_f32(c, own, s.up_proj_bias, D, &a.up_b, "adapter up_proj.bias"));
+        keep_first(rc, as_f32(c, own, s.scale, D, &a.scale, "adapter scale"));
         if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
         rc = load_decoder_layer(c, own, s.prior_layer, d, a.dl[0]);
         if (rc) return rc;
@@ -371,23 +396,31 @@ int load_adapters(hg_ctx* c, const hg_adapter_weights* src, int layers) {
 
 inline size_t rup(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
+// hipEvent pair around one launch when its kind is being profiled
+struct ProfScope {
+    hg_ctx* c;
+    hipStream_t s;
+    bool on;
+    ProfScope(hg_ctx* c_, hipStream_t s_, int kind, int M, int N, int K) : c(c_), s(s_), on(false) {
+        if (c->prof_kind == HG_PROF_OFF || (c->prof_kind != HG_PROF_ALL && c->prof_kind != kind)) return;
+        if (2 * c->prof_n + 1 >= c->prof_ev.size()) return;
+        if (hipEventRecord(c->prof_ev[2 * c->prof_n], s) != hipSuccess) return;
+        c->prof_rec[c->prof_n] = hg_prof_rec{kind, M, N, K, 0.f};
+        on = true;
+    }
+    ~ProfScope() {
+        if (on && hipEventRecord(c->prof_ev[2 * c->prof_n + 1], s) == hipSuccess) c->prof_n++;
+    }
+};
+
 hipError_t gemm(hg_ctx* c, int epi, const GemmArgs& g, hipStream_t s) {
-    // the LayerNorm-folding variants count as their base class (bench.py profiles the c_fc GEMM either way)
-    const int cls = epi == EPI_LN_BIAS_F16 ? EPI_BIAS_F16 : epi == EPI_LN_BIAS_QGELU_F16 ? EPI_BIAS_QGELU_F16
-                  : epi == EPI_RESID_LN_F32 ? EPI_BIAS_RESID_F32 : epi;
-    const bool prof = (c->prof_class == cls) && (2 * c->prof_n + 1 < c->prof_ev.size()) &&
-                      (c->prof_M == 0 || (c->prof_M == g.M && c->prof_N == g.N && c->prof_K == g.K));
-    if (prof) {
-        hipError_t e = hipEventRecord(c->prof_ev[2 * c->prof_n], s);
-        if (e != hipSuccess) return e;
-    }
-    hipError_t e = launch_gemm(epi, g, s);
-    if (prof && e == hipSuccess) {
-        e = hipEventRecord(c->prof_ev[2 * c->prof_n + 1], s);
-        if (c->prof_n == 0) { c->prof_flops = gemm_flops(g); c->prof_M = g.M; c->prof_N = g.N; c->prof_K = g.K; }
-        c->prof_n++;
-    }
-    return e;
+    ProfScope ps(c, s, epi, g.M, g.N, g.K);
+    return launch_gemm(epi, g, s);
+}
+
+hipError_t attention(hg_ctx* c, const half_t* qkv, half_t* out, int n_seq, int L, int heads, bool causal, hipStream_t s) {
+    ProfScope ps(c, s, HG_PROF_ATTENTION, n_seq, L, heads);
+    return launch_attention(qkv, out, n_seq, L, heads, causal, s);
 }
 
 // ---- one transformer tower over the residual stream in c->x ------------------------------------------
@@ -508,7 +541,7 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
             *row0_out = cx;
             break;
         }
-        HG_HIP(launch_attention(qkv, att, n_seq, L, heads, causal, s));
+        HG_HIP(attention(c, qkv, att, n_seq, L, heads, causal, s));
         g = GemmArgs{};
         g.A = att; g.lda = D; g.W = b.w_out; g.bias = b.b_out; g.out = x; g.ldc = D; g.M = M; g.N = D; g.K = D;
         if (fuse) {
@@ -545,12 +578,12 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
 int ensure_tower_ws(hg_ctx* c, int M, int D) {
     const size_t Mp = rup(M, 256);
     int rc = 0;
-    rc |= ensure(c, c->x, Mp * D * 4);
-    rc |= ensure(c, c->h, Mp * D * 2);
-    rc |= ensure(c, c->qkv, Mp * 3 * D * 2);
-    rc |= ensure(c, c->att, Mp * D * 2);
-    rc |= ensure(c, c->fc, Mp * 4 * D * 2);
-    return rc ? HG_ERR_OOM : HG_OK;
+    keep_first(rc, ensure(c, c->x, Mp * D * 4));
+    keep_first(rc, ensure(c, c->h, Mp * D * 2));
+    keep_first(rc, ensure(c, c->qkv, Mp * 3 * D * 2));
+    keep_first(rc, ensure(c, c->att, Mp * D * 2));
+    keep_first(rc, ensure(c, c->fc, Mp * 4 * D * 2));
+    return rc;
 }
 
 int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const AdapterCall& ac, hipStream_t s) {
@@ -593,7 +626,10 @@ const char* hg_version(void) { return "hoigen_amd 0.1 (gfx950)"; }
 hg_ctx* hg_create(int device) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return nullptr;
-    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (hipSetDevice(device) != hipSuccess) return nullptr;      // creates the primary context if needed
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
     hg_ctx* c = new hg_ctx();
     c->device = device;
     return c;
@@ -601,7 +637,7 @@ hg_ctx* hg_create(int device) {
 
 void hg_destroy(hg_ctx* c) {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    DevGuard dev_guard_(c);
     (void)hipDeviceSynchronize();
     free_all(c->vit.owned);
     free_all(c->vit.owned_adapters);
@@ -628,7 +664,7 @@ int hg_preprocess_crops(hg_ctx* c, const uint8_t* img, int H, int W, const int32
     if (!img || !boxes_host || !out || n < 0 || H <= 0 || W <= 0 || n_px <= 0 || n_px > 4096)
         return fail(c, HG_ERR_INVALID, "hg_preprocess_crops: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    HG_HIP(hipSetDevice(c->device));
+    HG_ON_DEVICE(c);
     // host part: geometry of every crop (sizes, padding, resize target, centre-crop offsets, tap counts, the
     // source rows the vertical pass needs); the weight tables themselves are filled on the device
     std::vector<int32_t> head((size_t)n * (HG_PRE_HDR + 1), 0);      // headers, then the n table offsets
@@ -694,7 +730,7 @@ int hg_test_gemm(hg_ctx* c, const float* a, const float* w, const float* bias, f
                  int epi, int kernel, void* stream) {
     if (!c || !a || !w || !out || M <= 0) return HG_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    HG_HIP(hipSetDevice(c->device));
+    HG_ON_DEVICE(c);
     int rc = ensure(c, c->h, rup(M, 256) * K * 2);
     if (!rc) rc = ensure(c, c->att, (size_t)N * K * 2);
     const bool f16out = (epi == EPI_BIAS_F16 || epi == EPI_BIAS_QGELU_F16 || epi == EPI_BIAS_RELU_F16);
@@ -718,7 +754,7 @@ int hg_test_attention(hg_ctx* c, const float* qkv, const float* q0, const int32_
                       int causal, float* out, void* stream) {
     if (!c || !qkv || !out || n_seq <= 0 || L < 1 || L > 224 || heads < 1) return HG_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    HG_HIP(hipSetDevice(c->device));
+    HG_ON_DEVICE(c);
     const int D = heads * 64;
     const size_t M = (size_t)n_seq * L;
     int rc = ensure(c, c->qkv, rup(M, 256) * 3 * D * 2);
@@ -738,36 +774,37 @@ int hg_test_attention(hg_ctx* c, const float* qkv, const float* q0, const int32_
     return HG_OK;
 }
 
-int hg_profile_begin(hg_ctx* c, int gemm_class, int max_launches) {
+int hg_profile_begin(hg_ctx* c, int kind, int max_launches) {
     if (!c || max_launches < 0) return HG_ERR_INVALID;
-    HG_HIP(hipSetDevice(c->device));
+    HG_ON_DEVICE(c);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     c->prof_ev.clear();
-    c->prof_n = 0; c->prof_flops = 0.0; c->prof_M = c->prof_N = c->prof_K = 0;
-    c->prof_class = gemm_class;
-    if (gemm_class < 0) return HG_OK;
+    c->prof_rec.clear();
+    c->prof_n = 0;
+    c->prof_kind = kind;
+    if (kind == HG_PROF_OFF) return HG_OK;
     c->prof_ev.resize((size_t)2 * max_launches);
+    c->prof_rec.resize((size_t)max_launches);
     for (auto& e : c->prof_ev) HG_HIP(hipEventCreate(&e));
     return HG_OK;
 }
 
-int hg_profile_end(hg_ctx* c, double* avg_ms, int32_t* launches, double* flops_per_launch, int32_t* mnk) {
-    if (!c || !avg_ms || !launches || !flops_per_launch) return HG_ERR_INVALID;
-    HG_HIP(hipSetDevice(c->device));
-    double tot = 0.0;
-    for (size_t i = 0; i < c->prof_n; ++i) {
+int hg_profile_end(hg_ctx* c, hg_prof_rec* recs, int max_recs, int32_t* n_recs) {
+    if (!c || !n_recs || (max_recs > 0 && !recs)) return HG_ERR_INVALID;
+    HG_ON_DEVICE(c);
+    int n = 0;
+    for (size_t i = 0; i < c->prof_n && n < max_recs; ++i, ++n) {
         HG_HIP(hipEventSynchronize(c->prof_ev[2 * i + 1]));
         float ms = 0.f;
         HG_HIP(hipEventElapsedTime(&ms, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
-        tot += ms;
+        recs[n] = c->prof_rec[i];
+        recs[n].ms = ms;
     }
-    *launches = (int32_t)c->prof_n;
-    *avg_ms = c->prof_n ? tot / (double)c->prof_n : 0.0;
-    *flops_per_launch = c->prof_flops;
-    if (mnk) { mnk[0] = c->prof_M; mnk[1] = c->prof_N; mnk[2] = c->prof_K; }
+    *n_recs = n;
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     c->prof_ev.clear();
-    c->prof_class = -1;
+    c->prof_rec.clear();
+    c->prof_kind = HG_PROF_OFF;
     c->prof_n = 0;
     return HG_OK;
 }
@@ -785,7 +822,7 @@ int hg_workspace_bytes(hg_ctx* c, uint64_t* bytes) {
 // ---- weights --------------------------------------------------------------------------------------------
 int hg_load_vit(hg_ctx* c, const hg_vit_weights* w) {
     if (!c || !w) return HG_ERR_INVALID;
-    HG_HIP(hipSetDevice(c->device));
+    HG_ON_DEVICE(c);
     Vit& v = c->vit;
     free_all(v.owned);
     free_all(v.owned_adapters);
@@ -802,14 +839,14 @@ int hg_load_vit(hg_ctx* c, const hg_vit_weights* w) {
     v.grid = v.res / p; v.L = v.grid * v.grid + 1; v.E = w->output_dim; v.Kp = 3 * p * p;
     if (v.L > 224) return fail(c, HG_ERR_INVALID, "at most 224 tokens per image supported (got %d)", v.L);
     int rc = 0;
-    rc |= as_f16(c, v.owned, w->conv1_weight, (size_t)D * v.Kp, &v.w_patch, "visual.conv1.weight");
-    rc |= as_f32(c, v.owned, w->class_embedding, D, &v.cls, "visual.class_embedding");
-    rc |= as_f32(c, v.owned, w->positional_embedding, (size_t)v.L * D, &v.pos, "visual.positional_embedding");
-    rc |= as_f32(c, v.owned, w->ln_pre_weight, D, &v.lnpre_w, "visual.ln_pre.weight");
-    rc |= as_f32(c, v.owned, w->ln_pre_bias, D, &v.lnpre_b, "visual.ln_pre.bias");
-    rc |= as_f32(c, v.owned, w->ln_post_weight, D, &v.lnpost_w, "visual.ln_post.weight");
-    rc |= as_f32(c, v.owned, w->ln_post_bias, D, &v.lnpost_b, "visual.ln_post.bias");
-    rc |= as_f16_T(c, v.owned, w->proj, D, v.E, &v.w_projT, "visual.proj");
+    keep_first(rc, as_f16(c, v.owned, w->conv1_weight, (size_t)D * v.Kp, &v.w_patch, "visual.conv1.weight"));
+    keep_first(rc, as_f32(c, v.owned, w->class_embedding, D, &v.cls, "visual.class_embedding"));
+    keep_first(rc, as_f32(c, v.owned, w->positional_embedding, (size_t)v.L * D, &v.pos, "visual.positional_embedding"));
+    keep_first(rc, as_f32(c, v.owned, w->ln_pre_weight, D, &v.lnpre_w, "visual.ln_pre.weight"));
+    keep_first(rc, as_f32(c, v.owned, w->ln_pre_bias, D, &v.lnpre_b, "visual.ln_pre.bias"));
+    keep_first(rc, as_f32(c, v.owned, w->ln_post_weight, D, &v.lnpost_w, "visual.ln_post.weight"));
+    keep_first(rc, as_f32(c, v.owned, w->ln_post_bias, D, &v.lnpost_b, "visual.ln_post.bias"));
+    keep_first(rc, as_f16_T(c, v.owned, w->proj, D, v.E, &v.w_projT, "visual.proj"));
     if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
     rc = load_blocks(c, v.owned, w->blocks, v.layers, D, v.blocks, true);
     if (rc) return rc;
@@ -823,14 +860,14 @@ int hg_load_vit(hg_ctx* c, const hg_vit_weights* w) {
 int hg_update_adapters(hg_ctx* c, const hg_adapter_weights* adapters, int layers) {
     if (!c) return HG_ERR_INVALID;
     if (!c->vit.loaded) return fail(c, HG_ERR_NOT_LOADED, "hg_load_vit first");
-    HG_HIP(hipSetDevice(c->device));
+    HG_ON_DEVICE(c);
     HG_HIP(hipDeviceSynchronize());
     return load_adapters(c, adapters, layers);
 }
 
 int hg_load_text(hg_ctx* c, const hg_text_weights* w) {
     if (!c || !w) return HG_ERR_INVALID;
-    HG_HIP(hipSetDevice(c->device));
+    HG_ON_DEVICE(c);
     Text& t = c->text;
     free_all(t.owned);
     t = Text{};
@@ -843,11 +880,11 @@ int hg_load_text(hg_ctx* c, const hg_text_weights* w) {
     t.D = D; t.layers = w->layers; t.heads = w->heads; t.ctx = w->context_length; t.vocab = w->vocab_size;
     t.E = w->output_dim;
     int rc = 0;
-    rc |= as_f32(c, t.owned, w->token_embedding, (size_t)t.vocab * D, &t.tok, "token_embedding.weight");
-    rc |= as_f32(c, t.owned, w->positional_embedding, (size_t)t.ctx * D, &t.pos, "positional_embedding");
-    rc |= as_f32(c, t.owned, w->ln_final_weight, D, &t.lnf_w, "ln_final.weight");
-    rc |= as_f32(c, t.owned, w->ln_final_bias, D, &t.lnf_b, "ln_final.bias");
-    rc |= as_f16_T(c, t.owned, w->text_projection, D, t.E, &t.w_projT, "text_projection");
+    keep_first(rc, as_f32(c, t.owned, w->token_embedding, (size_t)t.vocab * D, &t.tok, "token_embedding.weight"));
+    keep_first(rc, as_f32(c, t.owned, w->positional_embedding, (size_t)t.ctx * D, &t.pos, "positional_embedding"));
+    keep_first(rc, as_f32(c, t.owned, w->ln_final_weight, D, &t.lnf_w, "ln_final.weight"));
+    keep_first(rc, as_f32(c, t.owned, w->ln_final_bias, D, &t.lnf_b, "ln_final.bias"));
+    keep_first(rc, as_f16_T(c, t.owned, w->text_projection, D, t.E, &t.w_projT, "text_projection"));
     if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
     rc = load_blocks(c, t.owned, w->blocks, t.layers, D, t.blocks, false);
     if (rc) return rc;
@@ -858,7 +895,7 @@ int hg_load_text(hg_ctx* c, const hg_text_weights* w) {
 
 int hg_load_vae(hg_ctx* c, int slot, const hg_vae_weights* w) {
     if (!c || !w || slot < 0 || slot >= HG_MAX_SLOTS) return HG_ERR_INVALID;
-    HG_HIP(hipSetDevice(c->device));
+    HG_ON_DEVICE(c);
     Vae& v = c->vae[slot];
     free_all(v.owned);
     v = Vae{};
@@ -867,29 +904,29 @@ int hg_load_vae(hg_ctx* c, int slot, const hg_vae_weights* w) {
     int rc = 0;
     if (w->enc_w0.ptr) {
         if (v.eh <= 0 || v.eh % 128) return fail(c, HG_ERR_INVALID, "enc_hidden must be a multiple of 128");
-        rc |= as_f16(c, v.owned, w->enc_w0, (size_t)v.eh * v.dim, &v.e_w0, "Encoder.net.0.weight");
-        rc |= as_f32(c, v.owned, w->enc_b0, v.eh, &v.e_b0, "Encoder.net.0.bias");
+        keep_first(rc, as_f16(c, v.owned, w->enc_w0, (size_t)v.eh * v.dim, &v.e_w0, "Encoder.net.0.weight"));
+        keep_first(rc, as_f32(c, v.owned, w->enc_b0, v.eh, &v.e_b0, "Encoder.net.0.bias"));
         // mean | log_var stacked into one [2*dim, eh] GEMM operand
         void* p;
-        rc |= dev_alloc(c, v.owned, (size_t)2 * v.dim * v.eh * 2, &p);
+        keep_first(rc, dev_alloc(c, v.owned, (size_t)2 * v.dim * v.eh * 2, &p));
         if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
         v.e_wml = (half_t*)p;
         std::vector<void*> sc;
         half_t *m, *l;
-        rc |= as_f16(c, sc, w->enc_mean_w, (size_t)v.dim * v.eh, &m, "Encoder.mean.weight");
-        rc |= as_f16(c, sc, w->enc_logvar_w, (size_t)v.dim * v.eh, &l, "Encoder.log_var.weight");
+        keep_first(rc, as_f16(c, sc, w->enc_mean_w, (size_t)v.dim * v.eh, &m, "Encoder.mean.weight"));
+        keep_first(rc, as_f16(c, sc, w->enc_logvar_w, (size_t)v.dim * v.eh, &l, "Encoder.log_var.weight"));
         if (!rc) {
             (void)hipDeviceSynchronize();
             (void)hipMemcpy(v.e_wml, m, (size_t)v.dim * v.eh * 2, hipMemcpyDeviceToDevice);
             (void)hipMemcpy(v.e_wml + (size_t)v.dim * v.eh, l, (size_t)v.dim * v.eh * 2, hipMemcpyDeviceToDevice);
         }
         free_all(sc);
-        rc |= dev_alloc(c, v.owned, (size_t)2 * v.dim * 4, &p);
+        keep_first(rc, dev_alloc(c, v.owned, (size_t)2 * v.dim * 4, &p));
         if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
         v.e_bml = (float*)p;
         float *bm, *bl;
-        rc |= as_f32(c, sc, w->enc_mean_b, v.dim, &bm, "Encoder.mean.bias");
-        rc |= as_f32(c, sc, w->enc_logvar_b, v.dim, &bl, "Encoder.log_var.bias");
+        keep_first(rc, as_f32(c, sc, w->enc_mean_b, v.dim, &bm, "Encoder.mean.bias"));
+        keep_first(rc, as_f32(c, sc, w->enc_logvar_b, v.dim, &bl, "Encoder.log_var.bias"));
         if (!rc) {
             (void)hipDeviceSynchronize();
             (void)hipMemcpy(v.e_bml, bm, (size_t)v.dim * 4, hipMemcpyDeviceToDevice);
@@ -901,10 +938,10 @@ int hg_load_vae(hg_ctx* c, int slot, const hg_vae_weights* w) {
     }
     if (w->gen_w0.ptr) {
         if (v.gh <= 0 || v.gh % 128) return fail(c, HG_ERR_INVALID, "gen_hidden must be a multiple of 128");
-        rc |= as_f16(c, v.owned, w->gen_w0, (size_t)v.gh * v.dim, &v.g_w0, "Generator.net.0.weight");
-        rc |= as_f32(c, v.owned, w->gen_b0, v.gh, &v.g_b0, "Generator.net.0.bias");
-        rc |= as_f16(c, v.owned, w->gen_w2, (size_t)v.dim * v.gh, &v.g_w2, "Generator.net.2.weight");
-        rc |= as_f32(c, v.owned, w->gen_b2, v.dim, &v.g_b2, "Generator.net.2.bias");
+        keep_first(rc, as_f16(c, v.owned, w->gen_w0, (size_t)v.gh * v.dim, &v.g_w0, "Generator.net.0.weight"));
+        keep_first(rc, as_f32(c, v.owned, w->gen_b0, v.gh, &v.g_b0, "Generator.net.0.bias"));
+        keep_first(rc, as_f16(c, v.owned, w->gen_w2, (size_t)v.dim * v.gh, &v.g_w2, "Generator.net.2.weight"));
+        keep_first(rc, as_f32(c, v.owned, w->gen_b2, v.dim, &v.g_b2, "Generator.net.2.bias"));
         if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
         v.gen = true;
     }
@@ -914,19 +951,19 @@ int hg_load_vae(hg_ctx* c, int slot, const hg_vae_weights* w) {
 
 int hg_load_mlp(hg_ctx* c, int slot, const hg_mlp_weights* w) {
     if (!c || !w || slot < 0 || slot >= HG_MAX_SLOTS) return HG_ERR_INVALID;
-    HG_HIP(hipSetDevice(c->device));
+    HG_ON_DEVICE(c);
     Mlp& m = c->mlp[slot];
     free_all(m.owned);
     m = Mlp{};
     m.in = w->in_dim; m.hid = w->hidden_dim; m.out = w->out_dim;
     if (m.in % 64 || m.hid % 128 || m.out % 128 || m.in <= 0) return fail(c, HG_ERR_INVALID, "mlp_net dims must be multiples of 128");
     int rc = 0;
-    rc |= as_f16(c, m.owned, w->w0, (size_t)m.hid * m.in, &m.w0, "mlp.net.0.weight");
-    rc |= as_f32(c, m.owned, w->b0, m.hid, &m.b0, "mlp.net.0.bias");
-    rc |= as_f16(c, m.owned, w->w2, (size_t)m.hid * m.hid, &m.w2, "mlp.net.2.weight");
-    rc |= as_f32(c, m.owned, w->b2, m.hid, &m.b2, "mlp.net.2.bias");
-    rc |= as_f16(c, m.owned, w->w4, (size_t)m.out * m.hid, &m.w4, "mlp.net.4.weight");
-    rc |= as_f32(c, m.owned, w->b4, m.out, &m.b4, "mlp.net.4.bias");
+    keep_first(rc, as_f16(c, m.owned, w->w0, (size_t)m.hid * m.in, &m.w0, "mlp.net.0.weight"));
+    keep_first(rc, as_f32(c, m.owned, w->b0, m.hid, &m.b0, "mlp.net.0.bias"));
+    keep_first(rc, as_f16(c, m.owned, w->w2, (size_t)m.hid * m.hid, &m.w2, "mlp.net.2.weight"));
+    keep_first(rc, as_f32(c, m.owned, w->b2, m.hid, &m.b2, "mlp.net.2.bias"));
+    keep_first(rc, as_f16(c, m.owned, w->w4, (size_t)m.out * m.hid, &m.w4, "mlp.net.4.weight"));
+    keep_first(rc, as_f32(c, m.owned, w->b4, m.out, &m.b4, "mlp.net.4.bias"));
     if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
     HG_HIP(hipDeviceSynchronize());
     m.loaded = true;
@@ -939,7 +976,7 @@ int hg_roi_align(hg_ctx* c, const float* feat, int C, int H, int W, const float*
     if (n == 0) return HG_OK;
     if (!feat || !boxes || n < 0 || C <= 0 || H <= 0 || W <= 0 || P <= 0 || (!out_pooled && !out_mean))
         return fail(c, HG_ERR_INVALID, "hg_roi_align: bad arguments");
-    HG_HIP(hipSetDevice(c->device));
+    HG_ON_DEVICE(c);
     HG_HIP(launch_roi_align(feat, C, H, W, boxes, n, spatial_scale, P, out_pooled, out_mean, (hipStream_t)stream));
     return HG_OK;
 }
@@ -967,7 +1004,7 @@ static int upload_f32(hg_ctx* c, std::vector<void*>& owned, const std::vector<fl
 
 int hg_load_cache(hg_ctx* c, int slot, const hg_cache_weights* w) {
     if (!c || !w || slot < 0 || slot >= HG_MAX_CACHE_SLOTS) return HG_ERR_INVALID;
-    HG_HIP(hipSetDevice(c->device));
+    HG_ON_DEVICE(c);
     Cache& m = c->cache[slot];
     free_all(m.owned);
     m = Cache{};
@@ -1034,7 +1071,7 @@ int hg_cache_logits(hg_ctx* c, int slot, const float* feats, int R, float* out, 
     if (R == 0) return HG_OK;
     if (R < 0 || !feats || !out) return fail(c, HG_ERR_INVALID, "bad arguments to cache_logits");
     hipStream_t s = (hipStream_t)stream;
-    HG_HIP(hipSetDevice(c->device));
+    HG_ON_DEVICE(c);
     for (int r0 = 0; r0 < R; r0 += c->max_chunk_rows) {
         const int Rc = (R - r0 < c->max_chunk_rows) ? R - r0 : c->max_chunk_rows;
         const size_t Rp = rup(Rc, 256);
@@ -1076,7 +1113,7 @@ static int encode_image_impl(hg_ctx* c, const float* x_nchw, const float* priors
     if (B < 0 || !x_nchw || !out) return fail(c, HG_ERR_INVALID, "bad arguments to encode_image");
     if (variant_c && !out_local) return fail(c, HG_ERR_INVALID, "out_local == NULL");
     if (priors && (N <= 0 || !mask)) return fail(c, HG_ERR_INVALID, "priors given but N <= 0 or mask == NULL");
-    HG_HIP(hipSetDevice(c->device));
+    HG_ON_DEVICE(c);
     const int D = v.D, L = v.L, G = L - 1, E = v.E;
     const size_t img = (size_t)3 * v.res * v.res;
     for (int b0 = 0; b0 < B; b0 += c->max_chunk_img) {
@@ -1168,7 +1205,7 @@ int hg_encode_text_ids(hg_ctx* c, const int32_t* ids, int T, int L, float* out, 
     if (T == 0) return HG_OK;
     if (T < 0 || !ids || !out || L < 1 || L > t.ctx) return fail(c, HG_ERR_INVALID, "bad arguments to encode_text_ids");
     hipStream_t s = (hipStream_t)stream;
-    HG_HIP(hipSetDevice(c->device));
+    HG_ON_DEVICE(c);
     const int Leff = (trunc > 0 && trunc < L) ? trunc : L;
     for (int t0 = 0; t0 < T; t0 += c->max_chunk_txt) {
         const int Tc = (T - t0 < c->max_chunk_txt) ? T - t0 : c->max_chunk_txt;
@@ -1195,7 +1232,7 @@ int hg_encode_text_embeds(hg_ctx* c, const float* prompts, const int32_t* eot_id
     if (R < 0 || !prompts || !eot_idx || !out || L < 1 || L > t.ctx)
         return fail(c, HG_ERR_INVALID, "bad arguments to encode_text_embeds");
     hipStream_t s = (hipStream_t)stream;
-    HG_HIP(hipSetDevice(c->device));
+    HG_ON_DEVICE(c);
     const int Leff = (trunc > 0 && trunc < L) ? trunc : L;
     for (int r0 = 0; r0 < R; r0 += c->max_chunk_txt) {
         const int Rc = (R - r0 < c->max_chunk_txt) ? R - r0 : c->max_chunk_txt;
@@ -1213,7 +1250,7 @@ int hg_token_embedding(hg_ctx* c, const int32_t* ids, int n, float* out, void* s
     if (!c) return HG_ERR_INVALID;
     if (!c->text.loaded) return fail(c, HG_ERR_NOT_LOADED, "hg_load_text has not been called");
     if (n < 0 || !ids || !out) return fail(c, HG_ERR_INVALID, "bad arguments to token_embedding");
-    HG_HIP(hipSetDevice(c->device));
+    HG_ON_DEVICE(c);
     HG_HIP(launch_gather_rows(ids, c->text.tok, out, n, c->text.D, c->text.vocab, (hipStream_t)stream));
     return HG_OK;
 }
@@ -1239,7 +1276,7 @@ int hg_vae_forward(hg_ctx* c, int slot, const float* x, const float* eps, int R,
     if (R == 0) return HG_OK;
     if (R < 0 || !x || !eps) return fail(c, HG_ERR_INVALID, "bad arguments to vae_forward");
     hipStream_t s = (hipStream_t)stream;
-    HG_HIP(hipSetDevice(c->device));
+    HG_ON_DEVICE(c);
     const int dim = v.dim;
     for (int r0 = 0; r0 < R; r0 += c->max_chunk_rows) {
         const int Rc = (R - r0 < c->max_chunk_rows) ? R - r0 : c->max_chunk_rows;
@@ -1279,7 +1316,7 @@ int hg_generator(hg_ctx* c, int slot, const float* z, int R, float* bias, void* 
     if (R == 0) return HG_OK;
     if (R < 0 || !z || !bias) return fail(c, HG_ERR_INVALID, "bad arguments to generator");
     hipStream_t s = (hipStream_t)stream;
-    HG_HIP(hipSetDevice(c->device));
+    HG_ON_DEVICE(c);
     for (int r0 = 0; r0 < R; r0 += c->max_chunk_rows) {
         const int Rc = (R - r0 < c->max_chunk_rows) ? R - r0 : c->max_chunk_rows;
         const size_t Rp = rup(Rc, 256);
@@ -1301,7 +1338,7 @@ int hg_mlp_net(hg_ctx* c, int slot, const float* x, int R, float* out, void* str
     if (R == 0) return HG_OK;
     if (R < 0 || !x || !out) return fail(c, HG_ERR_INVALID, "bad arguments to mlp_net");
     hipStream_t s = (hipStream_t)stream;
-    HG_HIP(hipSetDevice(c->device));
+    HG_ON_DEVICE(c);
     for (int r0 = 0; r0 < R; r0 += c->max_chunk_rows) {
         const int Rc = (R - r0 < c->max_chunk_rows) ? R - r0 : c->max_chunk_rows;
         const size_t Rp = rup(Rc, 256);
@@ -1331,7 +1368,7 @@ int hg_assemble_prompts(hg_ctx* c, const float* prefix, const float* suffix, con
     if (!c) return HG_ERR_INVALID;
     if (!prefix || !suffix || !ctx || !bias || !target || !prompts || R < 0 || C <= 0)
         return fail(c, HG_ERR_INVALID, "bad arguments to assemble_prompts");
-    HG_HIP(hipSetDevice(c->device));
+    HG_ON_DEVICE(c);
     HG_HIP(launch_assemble_prompts(prefix, suffix, ctx, bias, target, R, C, L, n_ctx, D, prompts, (hipStream_t)stream));
     return HG_OK;
 }
@@ -1339,7 +1376,7 @@ int hg_assemble_prompts(hg_ctx* c, const float* prefix, const float* suffix, con
 int hg_l2_normalize(hg_ctx* c, const float* x, int R, int D, float* out, void* stream) {
     if (!c) return HG_ERR_INVALID;
     if (!x || !out || R < 0 || D <= 0) return fail(c, HG_ERR_INVALID, "bad arguments to l2_normalize");
-    HG_HIP(hipSetDevice(c->device));
+    HG_ON_DEVICE(c);
     HG_HIP(launch_l2_normalize(x, out, R, D, (hipStream_t)stream));
     return HG_OK;
 }
@@ -1348,7 +1385,7 @@ int hg_vae_loss(hg_ctx* c, const float* recon, const float* x, const float* mean
                 int D, float* loss, void* stream) {
     if (!c) return HG_ERR_INVALID;
     if (!recon || !x || !mean || !logvar || !loss || R <= 0) return fail(c, HG_ERR_INVALID, "bad arguments to vae_loss");
-    HG_HIP(hipSetDevice(c->device));
+    HG_ON_DEVICE(c);
     HG_HIP(launch_vae_loss(recon, x, mean, logvar, R, D, loss, (hipStream_t)stream));
     return HG_OK;
 }

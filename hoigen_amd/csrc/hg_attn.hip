@@ -191,7 +191,8 @@ static hipError_t launch_t(const half_t* qkv, half_t* out, int n_seq, int L, int
                            const half_t* q0 = nullptr, const int32_t* sel = nullptr) {
     const int nkt = (L + 31) / 32;
     const int lds = 2 * ((L + 15) & ~15) * ROWB;
-    static bool attr_set = false;
+    static bool attr_set_d[HG_MAX_DEVICES] = {};      // function attributes are per device
+    bool& attr_set = attr_set_d[current_device_index()];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<CAUSAL, ROW0>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 7 * TILEB);

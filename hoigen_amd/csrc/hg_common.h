@@ -11,6 +11,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
+#define HG_MAX_DEVICES 16
+// index of the calling thread's current HIP device for per-device launcher state (clamped)
+inline int current_device_index() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= HG_MAX_DEVICES) d = 0;
+    return d;
+}
+
 #define HG_LDS __attribute__((address_space(3)))
 #define HG_GLOBAL __attribute__((address_space(1)))
 

@@ -177,9 +177,13 @@ __global__ __launch_bounds__(256) void gemm_nt_128x128(const GemmArgs p) {
 
 template <int EPI>
 static hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
-    static int n_cu = 256;
+    static bool attr_set_d[HG_MAX_DEVICES] = {};      // function attributes and CU counts are per device
+    static int n_cu_d[HG_MAX_DEVICES];
+    const int dev_i = current_device_index();
+    bool& attr_set = attr_set_d[dev_i];
+    int& n_cu = n_cu_d[dev_i];
     if (!attr_set) {
+        n_cu = 256;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_128x128<EPI, 2>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         if (e == hipSuccess)

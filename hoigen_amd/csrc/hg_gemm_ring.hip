@@ -726,9 +726,13 @@ static hipError_t launch_ring_t(const GemmArgs& a, hipStream_t s) {
     constexpr bool LNC = (EPI == EPI_LN_BIAS_F16 || EPI == EPI_LN_BIAS_QGELU_F16);
     const int LDS = RING + a.N * 4 * (LNC ? 2 : 1) + (LNC ? BM * 8 : 0);   // ring + bias[N] (+ cs[N] + (mean, rstd)[BM])
     if (LDS > 160 * 1024) return hipErrorInvalidValue;
-    static bool attr_set = false;
-    static int n_cu = 256;
+    static bool attr_set_d[HG_MAX_DEVICES] = {};      // function attributes and CU counts are per device
+    static int n_cu_d[HG_MAX_DEVICES];
+    const int dev_i = current_device_index();
+    bool& attr_set = attr_set_d[dev_i];
+    int& n_cu = n_cu_d[dev_i];
     if (!attr_set) {
+        n_cu = 256;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring<MF, EPI, PH2>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;

@@ -509,9 +509,13 @@ static hipError_t launch_ring2_t(const GemmArgs& a, hipStream_t s) {
     constexpr int RING = 3 * 49152;
     const int LDS = RING + a.N * 4;
     if (LDS > 160 * 1024) return hipErrorInvalidValue;
-    static bool attr_set = false;
-    static int n_cu = 256;
+    static bool attr_set_d[HG_MAX_DEVICES] = {};      // function attributes and CU counts are per device
+    static int n_cu_d[HG_MAX_DEVICES];
+    const int dev_i = current_device_index();
+    bool& attr_set = attr_set_d[dev_i];
+    int& n_cu = n_cu_d[dev_i];
     if (!attr_set) {
+        n_cu = 256;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring2<EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;

@@ -18,6 +18,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import random
+import weakref
 from collections import OrderedDict
 from typing import List, Optional, Tuple, Union
 
@@ -316,6 +317,22 @@ class VisionTransformer(nn.Module):
         return glob.to(out_dtype), local.to(out_dtype)
 
     @torch.no_grad()
+    def encode_into(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """Variant A ``forward`` writing the fp32 embeddings into the caller's contiguous ``out [B,E]`` (e.g. this
+        rank's slice of a pre-allocated all-gather buffer): no allocation, no dtype round trip."""
+        _require_cuda(x, "image batch")
+        if self.returns_local:
+            raise RuntimeError("hoigen_amd: encode_into is the variant-A (global embedding) path")
+        B, E = x.shape[0], self.output_dim
+        if out.dtype != torch.float32 or tuple(out.shape) != (B, E) or not out.is_contiguous() or out.device != x.device:
+            raise RuntimeError(f"hoigen_amd: out must be a contiguous fp32 [{B},{E}] tensor on {x.device}")
+        h = self._sync(x.device)
+        xf = x.detach().to(torch.float32).contiguous()
+        self._ctx.check(_lib.lib().hg_encode_image(h, xf.data_ptr(), B, out.data_ptr(), _stream_ptr(x.device)),
+                        "hg_encode_image")
+        return out
+
+    @torch.no_grad()
     def forward_trace(self, x: torch.Tensor):
         """Test hook: (embedding [B,E], CLS rows after ln_pre and every block [layers+1,B,D])."""
         _require_cuda(x, "image batch")
@@ -378,6 +395,7 @@ class CLIP(nn.Module):
         self._text_sig = None
         #: run the causal text tower only up to max(EOT)+1 positions (identical selected outputs)
         self.truncate_text = True
+        self._trunc_memo = (None, 0, 0)
 
     def initialize_parameters(self):
         """clipnet/model.py:295-322."""
@@ -424,6 +442,19 @@ class CLIP(nn.Module):
             self._text_sig = sig
         return h
 
+    def _trunc_len(self, tokens: torch.Tensor, eot: Optional[torch.Tensor] = None) -> int:
+        """max(EOT) + 1 over the call.  The grid depends on it, so the host has to read it: one tiny device->host
+        copy, remembered for the token tensor it was computed from (the sampling loop passes the same
+        ``tokenized_prompts`` every iteration, main_tip_finetune.py:759-824)."""
+        ref, ver, n = self._trunc_memo
+        if ref is not None and ref() is tokens and ver == tokens._version:      # the very same live tensor object
+            return n
+        if eot is None:
+            eot = tokens.argmax(dim=-1)
+        n = int(eot.max().item()) + 1
+        self._trunc_memo = (weakref.ref(tokens), tokens._version, n)
+        return n
+
     # -- public API -----------------------------------------------------------------------------------
     def encode_image(self, image: torch.Tensor):
         """clipnet/model.py:336-337 / CLIP_models_adapter_prior2.py:875-876."""
@@ -440,7 +471,7 @@ class CLIP(nn.Module):
         T, L = text.shape
         trunc = 0
         if self.truncate_text and T > 0:
-            trunc = int(text.argmax(dim=-1).max().item()) + 1     # one host read of a tiny tensor
+            trunc = self._trunc_len(text)
         ids = text.detach().to(device=dev, dtype=torch.int32).contiguous()
         out = torch.empty(T, self.text_projection.shape[1], device=dev, dtype=torch.float32)
         self._ctx.check(_lib.lib().hg_encode_text_ids(h, ids.data_ptr(), T, L, out.data_ptr(), trunc,
@@ -457,7 +488,7 @@ class CLIP(nn.Module):
         if D != self.transformer.width or L > self.context_length:
             raise RuntimeError(f"hoigen_amd: prompts must be [R,<= {self.context_length},{self.transformer.width}]")
         eot = tokenized_prompts.argmax(dim=-1)
-        trunc = (int(eot.max().item()) + 1) if (self.truncate_text and R > 0) else 0
+        trunc = self._trunc_len(tokenized_prompts, eot) if (self.truncate_text and R > 0) else 0
         eot32 = eot.to(device=dev, dtype=torch.int32).contiguous()
         pf = prompts.detach().to(torch.float32).contiguous()
         out = torch.empty(R, self.text_projection.shape[1], device=dev, dtype=torch.float32)

@@ -264,6 +264,7 @@ class _PromptLearner(nn.Module):
         self.register_buffer("token_suffix", embedding[:, 1 + self.n_ctx:, :].contiguous())
         self.tokenized_prompts = tokenized
         self._names_key = key
+        self._f32_key = None              # fp32 operands of hg_assemble_prompts are rebuilt on the next forward
 
     @torch.no_grad()
     def forward(self, bias: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
@@ -276,10 +277,18 @@ class _PromptLearner(nn.Module):
         L = 1 + self.n_ctx + Ls
         tgt = target.to(device=bias.device, dtype=torch.int32).contiguous()
         out = torch.empty(R, L, D, device=bias.device, dtype=torch.float32)
-        _util_ctx.check(_lib.lib().hg_assemble_prompts(
-            h, _f32(self.token_prefix).data_ptr(), _f32(self.token_suffix).data_ptr(), _f32(self.ctx).data_ptr(),
-            bf.data_ptr(), tgt.data_ptr(), R, C_, L, self.n_ctx, D, out.data_ptr(), _stream_ptr(bias.device)),
-            "hg_assemble_prompts")
+        # fp32 views of the (usually fp16: clip_model.dtype) buffers.  They are kept on the object: a temporary made
+        # inline (`_f32(t).data_ptr()`) is freed before the kernel is enqueued and its block can be handed to the
+        # next temporary.  Rebuilt when the buffers or ctx change (get_prefix_suffix_token, load_state_dict, .to()).
+        key = _sig([self.token_prefix, self.token_suffix, self.ctx]) + (str(bias.device),)
+        if key != getattr(self, "_f32_key", None):
+            self._f32_ops = tuple(_f32(t).to(bias.device) for t in (self.token_prefix, self.token_suffix, self.ctx))
+            self._f32_key = key
+        pre, suf, ctx = self._f32_ops
+        with torch.cuda.device(bias.device):
+            _util_ctx.check(_lib.lib().hg_assemble_prompts(
+                h, pre.data_ptr(), suf.data_ptr(), ctx.data_ptr(), bf.data_ptr(), tgt.data_ptr(), R, C_, L, self.n_ctx,
+                D, out.data_ptr(), _stream_ptr(bias.device)), "hg_assemble_prompts")
         return out
 
 

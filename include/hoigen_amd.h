@@ -222,12 +222,25 @@ int hg_vae_loss(hg_ctx*, const float* recon, const float* x, const float* mean, 
 
 /* ---- introspection for bench.py (no reference counterpart) --------------------------------- */
 int hg_workspace_bytes(hg_ctx*, uint64_t* bytes);
-/* Live per-kernel timing: from hg_profile_begin until hg_profile_end every launch of the GEMM kernel
- * with epilogue class `gemm_class` (0 bias->f16 [QKV], 1 bias+QuickGELU->f16 [c_fc], 3 bias+residual
- * [out_proj, c_proj], ...; only launches with the same M,N,K as the first one are counted) is
- * bracketed by a hipEvent pair on its own stream.  hg_profile_end synchronises and returns the mean
- * duration, the launch count, the algorithmic FLOPs of one launch (2*M*N*K) and {M,N,K}. */
-int hg_profile_begin(hg_ctx*, int gemm_class, int max_launches);
+/* Live per-kernel timing: from hg_profile_begin until hg_profile_end every launch of kernel kind `kind` (or, with
+ * HG_PROF_ALL, every GEMM and attention launch of the towers and the VAE) is bracketed by a hipEvent pair on the
+ * stream it is launched on (an event record costs a few microseconds on the stream: profile a few steps, not all).
+ * GEMM kinds are the epilogue classes: 0 bias->f16, 1 bias+QuickGELU->f16, 2 bias+ReLU->f16, 3 bias+residual f32,
+ * 4 bias->f32, 5 patch embedding, 6 bias+ReLU->f32, 7 scale+residual, 8 LayerNorm-folded bias->f16 [QKV],
+ * 9 LayerNorm-folded bias+QuickGELU->f16 [c_fc], 10 residual + fp16 copy + row statistics [out_proj, c_proj],
+ * 11 the fused CoOp-VAE kernel (M rows; N, K = hidden sizes).  hg_profile_end synchronises and returns one record per
+ * timed launch, in launch order. */
+#define HG_PROF_OFF (-1)
+#define HG_PROF_ALL (-2)
+#define HG_PROF_ATTENTION 100 /* M = sequences, N = tokens per sequence, K = heads */
+#define HG_PROF_VAE 11
+typedef struct {
+    int32_t kind; /* GEMM epilogue class, HG_PROF_ATTENTION or HG_PROF_VAE */
+    int32_t M, N, K;
+    float ms;
+} hg_prof_rec;
+int hg_profile_begin(hg_ctx*, int kind, int max_launches);
+int hg_profile_end(hg_ctx*, hg_prof_rec* recs, int max_recs, int32_t* n_recs);
 /* Test hook for the GEMM kernels: out[M,N] fp32 = epilogue(fp16(a[M,K]) x fp16(w[N,K])^T) (for the residual
  * epilogue `out` is read-modify-written).  epi: 0 bias->f16, 1 bias+QuickGELU->f16, 2 bias+ReLU->f16,
  * 3 bias+residual(f32), 4 bias->f32, 6 bias+ReLU->f32.  kernel: 0 auto, 1 simple 128x128, 2 persistent ring. */
@@ -239,7 +252,6 @@ int hg_test_gemm(hg_ctx*, const float* a, const float* w, const float* bias, flo
  * row 0 when sel is NULL - the row index only matters for the causal mask), out [n_seq, heads*64]. */
 int hg_test_attention(hg_ctx*, const float* qkv, const float* q0, const int32_t* sel, int n_seq, int L, int heads,
                       int causal, float* out, void* stream);
-int hg_profile_end(hg_ctx*, double* avg_ms, int32_t* launches, double* flops_per_launch, int32_t* mnk);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from hoigen_amd.distributed import all_gather_rows, encode_image_sharded, shard_bounds
+from hoigen_amd.distributed import ShardedEncoder, all_gather_rows, encode_image_sharded, shard_bounds
 
 
 def test_shard_bounds_cover_exactly():
@@ -35,7 +35,22 @@ def _worker(rank, world, port, n, out_q):
     ok = torch.equal(full, _fake_encode(images))
     lo, hi = shard_bounds(n, world, rank)
     ok2 = torch.equal(all_gather_rows(_fake_encode(images[lo:hi]), n), _fake_encode(images))
-    out_q.put((rank, bool(ok and ok2)))
+    # steady-state form: equal local batches written into the rank's slice of a pre-allocated buffer
+    ok3 = True
+    if n % world == 0:
+        bl = n // world
+
+        def into(x, out):
+            out.copy_(_fake_encode(x))
+            return out
+
+        enc = ShardedEncoder(into, bl, 3, torch.device("cpu"))
+        for it in range(3):                                   # buffers alternate and are reused
+            imgs = images + it
+            buf, ev = enc.step(imgs[rank * bl:(rank + 1) * bl])
+            ok3 = ok3 and ev is None and torch.equal(buf, _fake_encode(imgs))
+        enc.finish()
+    out_q.put((rank, bool(ok and ok2 and ok3)))
     dist.destroy_process_group()
 
 
