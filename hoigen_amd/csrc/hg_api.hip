@@ -408,9 +408,11 @@ struct ProfScope {
         c->prof_rec[c->prof_n] = hg_prof_rec{kind, M, N, K, 0.f};
         on = true;
     }
-    ~ProfScope() {
+    void finish() {
         if (on && hipEventRecord(c->prof_ev[2 * c->prof_n + 1], s) == hipSuccess) c->prof_n++;
+        on = false;
     }
+    ~ProfScope() { finish(); }
 };
 
 hipError_t gemm(hg_ctx* c, int epi, const GemmArgs& g, hipStream_t s) {
@@ -632,6 +634,10 @@ hg_ctx* hg_create(int device) {
     if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
     hg_ctx* c = new hg_ctx();
     c->device = device;
+    if (const char* e = getenv("HG_CHUNK_ROWS")) {          // tuning knob: rows per VAE / mlp_net / cache-logits chunk
+        const int v = atoi(e);
+        if (v >= 256) c->max_chunk_rows = v;
+    }
     return c;
 }
 
@@ -742,9 +748,12 @@ int hg_test_gemm(hg_ctx* c, const float* a, const float* w, const float* bias, f
     g.A = (half_t*)c->h.p; g.lda = K; g.W = (half_t*)c->att.p; g.bias = bias; g.M = M; g.N = N; g.K = K;
     g.out = f16out ? c->qkv.p : (void*)out; g.ldc = N;
     hipError_t e;
+    ProfScope ps(c, s, epi, M, N, K);
     if (kernel == 1) e = launch_gemm_simple(epi, g, s);
     else if (kernel == 2) e = gemm_ring_ok(g) ? launch_gemm_ring(epi, g, s) : hipErrorInvalidValue;
+    else if (kernel == 3) e = gemm_duo_ok(epi, g) ? launch_gemm_duo(epi, g, s) : hipErrorInvalidValue;
     else e = launch_gemm(epi, g, s);
+    ps.finish();
     if (e != hipSuccess) return fail(c, HG_ERR_HIP, "test gemm launch failed: %s", hipGetErrorString(e));
     if (f16out) HG_HIP(launch_f16_to_f32((const half_t*)c->qkv.p, out, (size_t)M * N, s));
     return HG_OK;

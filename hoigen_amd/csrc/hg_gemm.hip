@@ -210,6 +210,12 @@ hipError_t launch_gemm(int epi, const GemmArgs& a, hipStream_t s) {
         return (e && e[0] == 's') ? 1 : 0;      // HG_GEMM=simple: A/B against the 128x128 kernel
     }();
     if (a.M <= 0) return hipSuccess;
+    // HG_DUO: 0 = never; 1 (default) = the plain residual GEMMs (text tower, the vision tower's last c_proj) run on the
+    // two-workgroups-per-CU kernel (117 / 293 us against 147 / 305 us of the ring kernels at M = 50432); 2 = every
+    // epilogue it implements except the LayerNorm-emitting residual (ring2 and duo tie there); 3 = that one as well
+    static const int duo = []() { const char* e = getenv("HG_DUO"); return e ? atoi(e) : 1; }();
+    const bool use_duo = duo >= 3 || (duo == 2 && epi != EPI_RESID_LN_F32) || (duo == 1 && epi == EPI_BIAS_RESID_F32);
+    if (!force_simple && use_duo && gemm_duo_ok(epi, a)) return launch_gemm_duo(epi, a, s);
     const bool ln = (epi == EPI_LN_BIAS_F16 || epi == EPI_LN_BIAS_QGELU_F16 || epi == EPI_RESID_LN_F32);
     if (ln) return gemm_ln_ok(epi, a) ? launch_gemm_ring(epi, a, s) : hipErrorInvalidValue;   // ring kernels only
     if (!force_simple && gemm_ring_ok(a)) return launch_gemm_ring(epi, a, s);

@@ -59,6 +59,9 @@ bool gemm_ring2_ok(const GemmArgs& a);
 bool gemm_ln_ok(int epi, const GemmArgs& a);
 hipError_t launch_gemm_ring2(int epi, const GemmArgs& a, hipStream_t s);
 hipError_t launch_gemm_simple(int epi, const GemmArgs& a, hipStream_t s);
+// two 4-wave workgroups per CU, 128x256 tiles, free-running (hg_gemm_duo.hip): residual GEMMs and fp16/fp32 outputs
+bool gemm_duo_ok(int epi, const GemmArgs& a);
+hipError_t launch_gemm_duo(int epi, const GemmArgs& a, hipStream_t s);
 
 // ---- attention: softmax(Q K^T / sqrt(64) [+causal]) V, head_dim 64 --------------------------
 // qkv fp16 [n_seq*L, 3*D] rows = tokens (q|k|v column blocks, head h = 64h..64h+63);

@@ -69,6 +69,9 @@ def test_gemm_kernels(ctx, M, N, K, epi):
     got2 = run(ctx, a, w, bias, epi, 2, out0)
     assert (got2 - want).abs().max().item() <= tol, "ring kernel"
     assert torch.equal(got1, got2), "ring and simple kernels accumulate in the same order"
+    if N % 256 == 0 and K >= 256 and M >= 512:      # two-workgroups-per-CU kernel (hg_gemm_duo.hip): same bits
+        assert torch.equal(got1, run(ctx, a, w, bias, epi, 3, out0)), "duo and simple kernels accumulate in the same order"
+        assert torch.equal(run(ctx, a, w, None, epi, 1, out0), run(ctx, a, w, None, epi, 3, out0)), "duo without bias"
     got_nb = run(ctx, a, w, None, epi, 2, out0)
     want_nb = ref(a, w, None, epi, out0)
     assert (got_nb - want_nb).abs().max().item() <= tol, "ring kernel without bias"
@@ -87,5 +90,6 @@ def test_ring_many_tiles_per_workgroup(ctx):
         for _ in range(3):                      # repeated launches: races would show as flaky mismatches
             g2 = run(ctx, a, w, bias, epi, 2, out0)
             assert torch.equal(g1, g2)
+            assert torch.equal(g1, run(ctx, a, w, bias, epi, 3, out0)), "duo kernel"
     want = ref(a, w, bias, 4, None)
     assert (g1 - want).abs().max().item() <= 2e-5 * want.abs().max().item()
