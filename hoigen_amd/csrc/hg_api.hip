@@ -1299,17 +1299,20 @@ int hg_vae_forward(hg_ctx* c, int slot, const float* x, const float* eps, int R,
         half_t* x16 = (half_t*)c->h.p;
         half_t* z16 = (half_t*)c->att.p;
         half_t* h1 = (half_t*)c->qkv.p;
-        float* ml = (float*)c->x.p;
+        float* ml = (float*)c->x.p;          // [2][Rp, dim] planes for the halves the caller did not ask for
         const size_t o = (size_t)r0 * dim;
+        float* mean_o = mean ? mean + o : ml;
+        float* lv_o = logvar ? logvar + o : ml + Rp * dim;
         HG_HIP(launch_f32_to_f16(x + o, x16, (size_t)Rc * dim, s));
         GemmArgs g{};
         g.A = x16; g.lda = dim; g.W = v.e_w0; g.bias = v.e_b0; g.out = h1; g.ldc = v.eh; g.M = Rc; g.N = v.eh; g.K = dim;
         HG_HIP(gemm(c, EPI_BIAS_RELU_F16, g, s));
+        // mean | log_var as ONE N = 2*dim GEMM whose two column halves land directly in the caller's tensors
         g = GemmArgs{};
-        g.A = h1; g.lda = v.eh; g.W = v.e_wml; g.bias = v.e_bml; g.out = ml; g.ldc = 2 * dim; g.M = Rc; g.N = 2 * dim; g.K = v.eh;
+        g.A = h1; g.lda = v.eh; g.W = v.e_wml; g.bias = v.e_bml; g.out = mean_o; g.out_hi = lv_o; g.n_split = dim; g.ldc = dim;
+        g.M = Rc; g.N = 2 * dim; g.K = v.eh;
         HG_HIP(gemm(c, EPI_BIAS_F32, g, s));
-        HG_HIP(launch_reparam(ml, eps + o, Rc, dim, mean ? mean + o : nullptr, logvar ? logvar + o : nullptr,
-                              z ? z + o : nullptr, z16, dim, s));
+        HG_HIP(launch_reparam(mean_o, lv_o, eps + o, Rc, dim, z ? z + o : nullptr, z16, dim, s));
         if (bias) {
             rc = generator_rows(c, v, z16, Rc, bias + o, s);
             if (rc) return rc;

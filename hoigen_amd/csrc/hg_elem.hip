@@ -235,22 +235,47 @@ hipError_t launch_eot_argmax(const int32_t* ids, int T, int L, int32_t* eot, int
 }
 
 // ---- dtype conversion / transposition (weight loading) ------------------------------------------------
-__global__ void f32_to_f16_kernel(const float* __restrict__ in, half_t* __restrict__ out, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = (half_t)in[i];
+// dtype conversions, HBM-bound: 8 elements per lane (2 x 16-byte loads -> one 16-byte store, and back) when the
+// pointers are 16-byte aligned, scalar otherwise and for the tail
+__global__ __launch_bounds__(256) void f32_to_f16_kernel(const float* __restrict__ in, half_t* __restrict__ out, size_t n,
+                                                         int vec) {
+    const size_t n8 = vec ? n / 8 : 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(in)[2 * i], b = reinterpret_cast<const f32x4*>(in)[2 * i + 1];
+        half8 h;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { h[k] = (half_t)a[k]; h[4 + k] = (half_t)b[k]; }
+        reinterpret_cast<half8*>(out)[i] = h;
+    }
+    for (size_t i = n8 * 8 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = (half_t)in[i];
 }
-__global__ void f16_to_f32_kernel(const half_t* __restrict__ in, float* __restrict__ out, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = (float)in[i];
+__global__ __launch_bounds__(256) void f16_to_f32_kernel(const half_t* __restrict__ in, float* __restrict__ out, size_t n,
+                                                         int vec) {
+    const size_t n8 = vec ? n / 8 : 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const half8 h = reinterpret_cast<const half8*>(in)[i];
+        f32x4 a, b;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a[k] = (float)h[k]; b[k] = (float)h[4 + k]; }
+        reinterpret_cast<f32x4*>(out)[2 * i] = a;
+        reinterpret_cast<f32x4*>(out)[2 * i + 1] = b;
+    }
+    for (size_t i = n8 * 8 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = (float)in[i];
 }
 hipError_t launch_f32_to_f16(const float* in, half_t* out, size_t n, hipStream_t s) {
     if (!n) return hipSuccess;
-    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(f32_to_f16_kernel, dim3(grid), dim3(256), 0, s, in, out, n);
+    const int vec = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+    const size_t work = vec ? (n + 7) / 8 : n;
+    const int grid = (int)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096);
+    hipLaunchKernelGGL(f32_to_f16_kernel, dim3(grid), dim3(256), 0, s, in, out, n, vec);
     return hipGetLastError();
 }
 hipError_t launch_f16_to_f32(const half_t* in, float* out, size_t n, hipStream_t s) {
     if (!n) return hipSuccess;
-    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(f16_to_f32_kernel, dim3(grid), dim3(256), 0, s, in, out, n);
+    const int vec = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+    const size_t work = vec ? (n + 7) / 8 : n;
+    const int grid = (int)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096);
+    hipLaunchKernelGGL(f16_to_f32_kernel, dim3(grid), dim3(256), 0, s, in, out, n, vec);
     return hipGetLastError();
 }
 __global__ void transpose_to_f16_kernel(const void* __restrict__ in, int in_dtype, half_t* __restrict__ out,
@@ -328,29 +353,33 @@ hipError_t launch_assemble_prompts(const float* prefix, const float* suffix, con
     return hipGetLastError();
 }
 
-// ---- reparameterise (main_coop_vae.py:445-447): ml = [mean | logvar] -------------------------------
-__global__ __launch_bounds__(256) void reparam_kernel(const float* __restrict__ ml, const float* __restrict__ eps,
-                                                      int R, int D, float* __restrict__ mean,
-                                                      float* __restrict__ logvar, float* __restrict__ z,
-                                                      half_t* __restrict__ z16, int ld16) {
-    const size_t total = (size_t)R * D;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const size_t r = i / D;
-        const int d = (int)(i - r * D);
-        const float m = ml[r * 2 * D + d], lv = ml[r * 2 * D + D + d];
-        const float zz = expf(0.5f * lv) * eps[i] + m;
-        if (mean) mean[i] = m;
-        if (logvar) logvar[i] = lv;
+// ---- reparameterise (main_coop_vae.py:445-447): z = exp(0.5 * log_var) * eps + mean ------------------------------
+// HBM-bound: 12 B read + 4 (+2) B written per element, 16-byte accesses.
+__global__ __launch_bounds__(256) void reparam_kernel(const f32x4* __restrict__ mean, const f32x4* __restrict__ logvar,
+                                                      const f32x4* __restrict__ eps, size_t total4, int D4,
+                                                      f32x4* __restrict__ z, half_t* __restrict__ z16, int ld16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const f32x4 m = mean[i], lv = logvar[i], e = eps[i];
+        f32x4 zz;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) zz[k] = expf(0.5f * lv[k]) * e[k] + m[k];
         if (z) z[i] = zz;
-        z16[r * ld16 + d] = (half_t)zz;
+        const size_t r = i / D4;
+        const int d4 = (int)(i - r * D4);
+        half4 h;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) h[k] = (half_t)zz[k];
+        *reinterpret_cast<half4*>(z16 + r * ld16 + 4 * d4) = h;
     }
 }
-hipError_t launch_reparam(const float* ml, const float* eps, int R, int D, float* mean, float* logvar, float* z,
-                          half_t* z16, int ld16, hipStream_t s) {
+hipError_t launch_reparam(const float* mean, const float* logvar, const float* eps, int R, int D, float* z, half_t* z16,
+                          int ld16, hipStream_t s) {
     if (R <= 0) return hipSuccess;
-    const size_t total = (size_t)R * D;
-    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(reparam_kernel, dim3(grid), dim3(256), 0, s, ml, eps, R, D, mean, logvar, z, z16, ld16);
+    if (D % 4 || ld16 % 4) return hipErrorInvalidValue;
+    const size_t total4 = (size_t)R * (D / 4);
+    const int grid = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(reparam_kernel, dim3(grid), dim3(256), 0, s, (const f32x4*)mean, (const f32x4*)logvar,
+                       (const f32x4*)eps, total4, D / 4, (f32x4*)z, z16, ld16);
     return hipGetLastError();
 }
 

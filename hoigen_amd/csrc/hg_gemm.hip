@@ -62,7 +62,9 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, int m, int n, f32x4 
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
         }
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v;
+        float* dst = (p.out_hi && n >= p.n_split) ? reinterpret_cast<float*>(p.out_hi) + (size_t)m * p.ldc + (n - p.n_split)
+                                                  : reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n;
+        *reinterpret_cast<f32x4*>(dst) = v;
     } else if constexpr (EPI == EPI_PATCH_F32) {
         const int b = m / p.G, t = m - b * p.G;
         const f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (size_t)(1 + t) * p.N + n);

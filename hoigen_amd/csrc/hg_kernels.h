@@ -42,6 +42,10 @@ struct GemmArgs {
     half_t* out2 = nullptr;      // EPI_RESID_LN: fp16 copy of the updated rows, leading dimension ldc
     float* stats = nullptr;      // EPI_RESID_LN: [M][stats_ld][2] partial (sum, sumsq) per row and wave column group
     int stats_ld = 0;            //   = 4 * N / 256
+    // EPI_BIAS_F32 / EPI_BIAS_RELU_F32 with two destinations: columns >= n_split go to out_hi[m * ldc + (n - n_split)]
+    // (the stacked mean | log_var GEMM of the VAE encoder writes its two halves straight into the caller's tensors)
+    void* out_hi = nullptr;
+    int n_split = 0;                     // multiple of 16
     unsigned long long* dbg = nullptr;   // diagnostics: s_memtime totals (HG_STAMPS build), normally null
 };
 
@@ -101,9 +105,10 @@ hipError_t launch_l2_normalize(const float* x, float* out, int R, int D, hipStre
 hipError_t launch_assemble_prompts(const float* prefix, const float* suffix, const float* ctx, const float* bias,
                                    const int32_t* target, int R, int C, int L, int n_ctx, int D, float* prompts,
                                    hipStream_t s);
-// ml [R, 2*D] = mean|logvar  ->  mean, logvar, z fp32 (optional) and z fp16 (GEMM operand)
-hipError_t launch_reparam(const float* ml, const float* eps, int R, int D, float* mean, float* logvar, float* z,
-                          half_t* z16, int ld16, hipStream_t s);
+// z = exp(0.5 * logvar) * eps + mean  (main_coop_vae.py:445-447) from the mean / logvar planes [R, D]: z fp32 (optional)
+// and z16 fp16 [R, ld16] (GEMM operand).  D % 4 == 0, 16-byte accesses.
+hipError_t launch_reparam(const float* mean, const float* logvar, const float* eps, int R, int D, float* z, half_t* z16,
+                          int ld16, hipStream_t s);
 hipError_t launch_vae_loss(const float* recon, const float* x, const float* mean, const float* logvar, int R,
                            int D, float* loss, hipStream_t s);
 // tokens [B*L, E] fp32 -> global [B,E] (token 0) and local [B,E,g,g] (tokens 1..), NCHW
