@@ -87,7 +87,7 @@ class hg_prof_rec(C.Structure):
     _fields_ = [("kind", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("ms", C.c_float)]
 
 
-HG_PROF_OFF, HG_PROF_ALL, HG_PROF_ATTENTION, HG_PROF_VAE = -1, -2, 100, 11
+HG_PROF_OFF, HG_PROF_ALL, HG_PROF_ATTENTION = -1, -2, 100
 
 _P = C.c_void_p
 _I = C.c_int

@@ -8,6 +8,8 @@
 // of 32, FFN 64-128-64, two LayerNorms) is 1.7 % of a block's FLOPs and runs in fp32 on the VALU:
 // one lane per token, the token's activations in a private LDS row, weights fetched with wave-uniform
 // (scalar-cache) loads so every FMA takes an SGPR weight operand.
+#include <stdlib.h>
+
 #include "hg_kernels.h"
 
 namespace hg {
@@ -175,6 +177,302 @@ __global__ __launch_bounds__(64) void adapter_decoder_kernel(const float* __rest
     }
 }
 
+// =====================================================================================================================
+// MFMA path of the same decoder layer: one workgroup (4 waves, 64 tokens each) per sequence.
+//
+// Every 64-wide linear runs as D = W . X^T on v_mfma_f32_16x16x32_f16 with the weight tile as the A operand and 16
+// token rows as the B operand, so an activation [64 tokens x 16g..] sits in registers as t[f][g] (f32x4): token
+// 16f + (lane & 15), features 16g + 4(lane >> 4) + r - the same "a lane holds 4 consecutive columns of one row" layout as
+// the GEMM kernels.  Between stages the activation goes through the wave's private LDS rows (fp16, 8-byte stores,
+// 16-byte fragment reads); weights are read from global memory (64 KB per layer, L2-resident) straight into fragments.
+// Attention: scores S[key][token] = K_h . Q_h^T per head (K = 32 features = one MFMA k-step), softmax over the keys of a
+// token across the lane's registers and its four lane rows, and P . V with the probabilities used as the B operand
+// exactly where the score accumulators left them (key order inside a 32-key block permuted; V^T is stored in LDS in
+// that order).  Residual stream of the layer, LayerNorm statistics and softmax stay in fp32.
+struct DecW16 {
+    const half_t *Wq, *Wk, *Wv, *Wo, *W1, *W2;      // fp16 [out][in]: 64x64 (x4), 128x64, 64x128
+    const float *bq, *bk, *bv, *bo, *b1, *b2, *norms;   // norms = {norm2.w, norm2.b, norm3.w, norm3.b}
+};
+
+static constexpr int XP = 136;      // halfs per row of a wave's activation buffer (64 or 128 features + pad)
+static constexpr int KP = 72;       // halfs per row of K [key][64]
+static constexpr int NKMAX = 224;   // keys: 14 tiles of 16 (L <= 224)
+static constexpr int VP = NKMAX + 8;   // halfs per row of V^T [feature][key slot]
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float max_rows(float x) {      // max over the four 16-lane rows
+    x = fmaxf(x, __shfl_xor(x, 16, 64));
+    return fmaxf(x, __shfl_xor(x, 32, 64));
+}
+__device__ __forceinline__ float sum_rows4(float x) {
+    x += __shfl_xor(x, 16, 64);
+    return x + __shfl_xor(x, 32, 64);
+}
+
+// t[f][g] (+)= W[16g.., :] . X[16f.., :]^T over K = 32 * KS features; W global fp16 [.][ldw], X = LDS rows of pitch XP
+template <int G, int KS>
+__device__ __forceinline__ void linear_T(f32x4 (&t)[4][G], const half_t* __restrict__ W, int ldw, const half_t* X, int lane) {
+    const int r = lane & 15, q = lane >> 4;
+    half8 xf[4][KS];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xf[f][ks] = *reinterpret_cast<const half8*>(X + (16 * f + r) * XP + 32 * ks + 8 * q);
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const half8 wf = *reinterpret_cast<const half8*>(W + (size_t)(16 * g + r) * ldw + 32 * ks + 8 * q);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) t[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[f][ks], t[f][g], 0, 0, 0);
+        }
+}
+template <int G>
+__device__ __forceinline__ void init_bias(f32x4 (&t)[4][G], const float* __restrict__ b, int lane) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(b + 16 * g + 4 * (lane >> 4));
+#pragma unroll
+        for (int f = 0; f < 4; ++f) t[f][g] = bv;
+    }
+}
+template <int G>
+__device__ __forceinline__ void store_T(const f32x4 (&t)[4][G], half_t* X, int lane) {
+    const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            half4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = (half_t)t[f][g][e];
+            *reinterpret_cast<half4*>(X + (16 * f + r) * XP + 16 * g + 4 * q) = h;
+        }
+}
+// LayerNorm over the 64 features of every token (eps 1e-5, biased variance), in place
+__device__ __forceinline__ void layer_norm_T(f32x4 (&t)[4][4], const float* __restrict__ w, const float* __restrict__ b, int lane) {
+    const int q = lane >> 4;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) s += (t[f][g][0] + t[f][g][1]) + (t[f][g][2] + t[f][g][3]);
+        const float mean = sum_rows4(s) * (1.0f / 64.0f);
+        float v = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = t[f][g][e] - mean;
+                v = fmaf(d, d, v);
+            }
+        const float rstd = 1.0f / sqrtf(sum_rows4(v) * (1.0f / 64.0f) + 1e-5f);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + 16 * g + 4 * q), bv = *reinterpret_cast<const f32x4*>(b + 16 * g + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[f][g][e] = (t[f][g][e] - mean) * rstd * wv[e] + bv[e];
+        }
+    }
+}
+
+// key index -> slot inside the V^T rows: within a block of 32 keys, key 16*kt + 4*q + r sits at 8*q + 4*kt + r, which is
+// where the score accumulators of key tiles (2b, 2b+1) put it when they are packed as the P.V B operand
+__device__ __forceinline__ int key_slot(int key) {
+    const int w = key & 31;
+    return (key & ~31) + 8 * ((w & 15) >> 2) + 4 * (w >> 4) + (w & 3);
+}
+
+template <bool SELF>
+__global__ __launch_bounds__(256) void adapter_decoder_mfma(const float* __restrict__ down, int ld_down, DecW16 W,
+                                                            const float* __restrict__ priors, const uint8_t* __restrict__ mask,
+                                                            int L, int N, half_t* __restrict__ out16) {
+    extern __shared__ __attribute__((aligned(16))) char smem_ad[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int seq = blockIdx.x;
+    const int nkeys = SELF ? L : N;
+    const int nkt = (nkeys + 15) >> 4;                  // key tiles of 16
+    const int nkb = (nkt + 1) >> 1;                     // key blocks of 32
+    half_t* Xw = reinterpret_cast<half_t*>(smem_ad) + wave * 64 * XP;        // this wave's activation rows
+    half_t* Ks = reinterpret_cast<half_t*>(smem_ad) + 4 * 64 * XP;           // K [key][KP]
+    half_t* VT = Ks + NKMAX * KP;                                            // V^T [feature][VP]
+    half_t* Mem = VT + 64 * VP;                                              // prior tokens fp16 [32][XP] (prior case)
+
+    // ---- this wave's 64 tokens: fp32 residual of the layer in registers, fp16 copy in LDS
+    f32x4 tgt[4][4];
+    int tok[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        tok[f] = wave * 64 + 16 * f + r;
+        const size_t m = (size_t)seq * L + (tok[f] < L ? tok[f] : L - 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) tgt[f][g] = *reinterpret_cast<const f32x4*>(down + m * ld_down + 16 * g + 4 * q);
+    }
+    store_T<4>(tgt, Xw, lane);
+    // ---- K and V of the memory tokens -> LDS (K row-major, V transposed with permuted key slots)
+    auto emit_kv = [&](const half_t* X, int key0) {       // 64 memory rows in X -> keys key0 ..
+        f32x4 kk[4][4], vv[4][4];
+        init_bias<4>(kk, W.bk, lane);
+        init_bias<4>(vv, W.bv, lane);
+        linear_T<4, 2>(kk, W.Wk, 64, X, lane);
+        linear_T<4, 2>(vv, W.Wv, 64, X, lane);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int key = key0 + 16 * f + r;
+            if (key < NKMAX) {
+                const int slot = key_slot(key);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    half4 h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[e] = (half_t)kk[f][g][e];
+                    *reinterpret_cast<half4*>(Ks + key * KP + 16 * g + 4 * q) = h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) VT[(16 * g + 4 * q + e) * VP + slot] = (half_t)vv[f][g][e];
+                }
+            }
+        }
+    };
+    if constexpr (SELF) {
+        emit_kv(Xw, wave * 64);                            // memory = the sequence's own tokens
+        __syncthreads();
+    } else {
+        // prior tokens [N <= 32][64] fp32 -> fp16 rows (rows >= N zero), then wave 0 projects them
+        for (int i = tid; i < 32 * 16; i += 256) {
+            const int row = i >> 4, c4 = (i & 15) * 4;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < N) v = *reinterpret_cast<const f32x4*>(priors + ((size_t)seq * N + row) * 64 + c4);
+            half4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
+            *reinterpret_cast<half4*>(Mem + row * XP + c4) = h;
+        }
+        for (int i = tid; i < 32 * 16; i += 256) {          // rows 32..63 of the fragment reads: zeros
+            *reinterpret_cast<half4*>(Mem + (32 + (i >> 4)) * XP + (i & 15) * 4) = half4{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+        }
+        __syncthreads();
+        if (wave == 0) emit_kv(Mem, 0);
+        __syncthreads();
+    }
+    // masked keys as a bit set (wave-uniform): bit k of word k >> 5
+    unsigned mbits[NKMAX / 32];
+#pragma unroll
+    for (int b = 0; b < NKMAX / 32; ++b) {
+        unsigned m = 0u;
+        if (b < nkb) {
+            const int key = 32 * b + (lane & 31);
+            bool dead = key >= nkeys;
+            if (!SELF && !dead && mask) dead = mask[(size_t)seq * N + key] != 0;
+            const unsigned long long bal = __ballot(dead);
+            m = (unsigned)bal;                               // lanes 0..31 carry keys 32b .. 32b+31
+        }
+        mbits[b] = __builtin_amdgcn_readfirstlane(m);
+    }
+
+    // ---- q = (Wq x + bq) / sqrt(32)
+    f32x4 t[4][4];
+    init_bias<4>(t, W.bq, lane);
+    linear_T<4, 2>(t, W.Wq, 64, Xw, lane);
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) t[f][g] *= 0.17677669529663687f;
+    store_T<4>(t, Xw, lane);                                  // (the fp16 copy of the input is no longer needed)
+    // ---- cross attention, 2 heads of 32
+    f32x4 att[4][4];
+#pragma unroll
+    for (int hd = 0; hd < 2; ++hd) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const half8 qf = *reinterpret_cast<const half8*>(Xw + (16 * f + r) * XP + 32 * hd + 8 * q);
+            f32x4 o0 = f32x4{0.f, 0.f, 0.f, 0.f}, o1 = o0;
+            // pass 1: scores of every key tile -> running maximum (scores are recomputed in pass 2: one MFMA per tile)
+            float mx = -INFINITY;
+            for (int kt = 0; kt < nkt; ++kt) {
+                const half8 kf = *reinterpret_cast<const half8*>(Ks + (16 * kt + r) * KP + 32 * hd + 8 * q);
+                f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                const unsigned mb = mbits[kt >> 1] >> (16 * (kt & 1) + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (!((mb >> e) & 1u)) mx = fmaxf(mx, s[e]);
+            }
+            mx = max_rows(mx);
+            float lsum = 0.f;
+            for (int b = 0; b < nkb; ++b) {
+                half8 pf;
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const int kt = 2 * b + k2;
+                    f32x4 s = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                    unsigned mb = 0xFu;
+                    if (kt < nkt) {
+                        const half8 kf = *reinterpret_cast<const half8*>(Ks + (16 * kt + r) * KP + 32 * hd + 8 * q);
+                        s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        mb = mbits[b] >> (16 * k2 + 4 * q);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float pe = ((mb >> e) & 1u) ? 0.f : __expf(s[e] - mx);
+                        lsum += pe;
+                        pf[4 * k2 + e] = (half_t)pe;
+                    }
+                }
+                const half8 v0 = *reinterpret_cast<const half8*>(VT + (32 * hd + r) * VP + 32 * b + 8 * q);
+                const half8 v1 = *reinterpret_cast<const half8*>(VT + (32 * hd + 16 + r) * VP + 32 * b + 8 * q);
+                o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0, pf, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1, pf, o1, 0, 0, 0);
+            }
+            const float inv = 1.0f / sum_rows4(lsum);
+            att[f][2 * hd] = o0 * inv;
+            att[f][2 * hd + 1] = o1 * inv;
+        }
+    }
+    // ---- out_proj, residual, norm2
+    store_T<4>(att, Xw, lane);
+    init_bias<4>(t, W.bo, lane);
+    linear_T<4, 2>(t, W.Wo, 64, Xw, lane);
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) tgt[f][g] += t[f][g];
+    layer_norm_T(tgt, W.norms, W.norms + 64, lane);
+    // ---- FFN 64 -> 128 (relu) -> 64, residual, norm3
+    store_T<4>(tgt, Xw, lane);
+    {
+        f32x4 hid[4][8];
+        init_bias<8>(hid, W.b1, lane);
+        linear_T<8, 2>(hid, W.W1, 64, Xw, lane);
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hid[f][g][e] = fmaxf(hid[f][g][e], 0.f);
+        store_T<8>(hid, Xw, lane);
+    }
+    init_bias<4>(t, W.b2, lane);
+    linear_T<4, 4>(t, W.W2, 128, Xw, lane);
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) tgt[f][g] += t[f][g];
+    layer_norm_T(tgt, W.norms + 128, W.norms + 192, lane);
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+        if (tok[f] < L) {
+            half_t* dst = out16 + ((size_t)seq * L + tok[f]) * AD;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                half4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = (half_t)tgt[f][g][e];
+                *reinterpret_cast<half4*>(dst + 16 * g + 4 * q) = h;
+            }
+        }
+}
+
 // down32 [M,128] fp32 (cols 0..63 = relu(down_proj(x))) -> out16 [M,64] fp16 = decoder layer output
 hipError_t launch_adapter_decoder(const float* down32, const AdapterDev& ad, const float* priors,
                                   const uint8_t* mask, int B, int L, int N, float* kv, half_t* out16,
@@ -184,6 +482,28 @@ hipError_t launch_adapter_decoder(const float* down32, const AdapterDev& ad, con
     const int Nmem = priors ? N : L;
     const int n_rows = B * Nmem;
     if (n_rows <= 0) return hipSuccess;
+    static const bool mfma_on = []() { const char* e = getenv("HG_ADAPTER_MFMA"); return !(e && e[0] == '0'); }();
+    if (mfma_on && ad.w16[which][0] && L <= NKMAX && (priors ? N <= 32 : true)) {
+        const half_t* const* w = ad.w16[which];
+        DecW16 Wd{w[0], w[1], w[2], w[3], w[4], w[5], dl[3], dl[4], dl[5], dl[7], dl[10], dl[11] + (size_t)2 * AD * AD, dl[8]};
+        const int lds = (4 * 64 * XP + NKMAX * KP + 64 * VP + 64 * XP) * 2;
+        static bool attr_set_d[HG_MAX_DEVICES] = {};
+        bool& attr_set = attr_set_d[current_device_index()];
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&adapter_decoder_mfma<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&adapter_decoder_mfma<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+        if (priors)
+            hipLaunchKernelGGL((adapter_decoder_mfma<false>), dim3(B), dim3(256), lds, s, down32, 128, Wd, priors, mask, L, N, out16);
+        else
+            hipLaunchKernelGGL((adapter_decoder_mfma<true>), dim3(B), dim3(256), lds, s, down32, 128, Wd, priors, mask, L, L, out16);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(adapter_kv_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, s, priors ? priors : down32,
                        priors ? AD : 128, n_rows, dl[1], dl[4], dl[2], dl[5], kv);
     DecoderPtrs P{dl[0], dl[3], dl[6], dl[7], dl[8], dl[9], dl[10], dl[11]};

@@ -44,10 +44,12 @@ struct AdapterW {
     int d = 0;
     half_t* down_w = nullptr;  // [128 (padded), D]
     float* down_b = nullptr;   // [128]
+    float* down_cs = nullptr;  // [128] row sums of the fp16 weight: down_proj on the CENTRED fp16 copy adds mu * cs back
     half_t* up_w = nullptr;    // [D, 64]
     float* up_b = nullptr;
     float* scale = nullptr;
     float* dl[2][12] = {};     // see AdapterDev
+    half_t* w16[2][6] = {};    // see AdapterDev
 };
 
 struct Vit {
@@ -106,7 +108,7 @@ struct hg_ctx {
     Mlp mlp[HG_MAX_SLOTS];
     Cache cache[HG_MAX_CACHE_SLOTS];
     // workspace (grow-only)
-    Buf x, h, qkv, att, fc, head16, tok32, small, i32, ad32, ad16, adkv, mr, mu, stats, pre, pretab, cx, ca, ch, cf, cq;
+    Buf x, h, qkv, att, fc, head16, tok32, small, i32, ad32, ad16, adkv, mr, mu, muc, stats, pre, pretab, cx, ca, ch, cf, cq;
     int max_chunk_img = 256;
     int max_chunk_txt = 640;
     int max_chunk_rows = 32768;
@@ -285,7 +287,16 @@ int load_blocks(hg_ctx* c, std::vector<void*>& owned, const hg_block_weights* sr
 }
 
 int load_decoder_layer(hg_ctx* c, std::vector<void*>& owned, const hg_decoder_layer_weights& s, int d,
-                       float* dl[12]) {
+                       float* dl[12], half_t* w16[6]) {
+    {      // fp16 [out][in] operands of the MFMA decoder: the state dict's own layout
+        half_t* inw16 = nullptr;
+        int r16 = as_f16(c, owned, s.attn_in_proj_weight, (size_t)3 * d * d, &inw16, "adapter in_proj_weight");
+        if (!r16) { w16[0] = inw16; w16[1] = inw16 + (size_t)d * d; w16[2] = inw16 + (size_t)2 * d * d; }
+        if (!r16) r16 = as_f16(c, owned, s.attn_out_proj_weight, (size_t)d * d, &w16[3], "adapter out_proj.weight");
+        if (!r16) r16 = as_f16(c, owned, s.linear1_weight, (size_t)2 * d * d, &w16[4], "adapter linear1.weight");
+        if (!r16) r16 = as_f16(c, owned, s.linear2_weight, (size_t)2 * d * d, &w16[5], "adapter linear2.weight");
+        if (r16) return r16;
+    }
     // 0 WqT [d,d] (in->out), 1 bq, 2 WkT, 3 bk, 4 WvT, 5 bv : split of in_proj;  6 WoT, 7 bo ... see below
     std::vector<void*> scratch;
     float* inw;
@@ -343,6 +354,8 @@ int load_decoder_layer(hg_ctx* c, std::vector<void*>& owned, const hg_decoder_la
     return rc ? (rc < 0 ? rc : HG_ERR_INVALID) : HG_OK;
 }
 
+int upload_f32(hg_ctx* c, std::vector<void*>& owned, const std::vector<float>& v, float** out);
+
 int load_adapters(hg_ctx* c, const hg_adapter_weights* src, int layers) {
     Vit& v = c->vit;
     free_all(v.owned_adapters);
@@ -380,13 +393,31 @@ int load_adapters(hg_ctx* c, const hg_adapter_weights* src, int layers) {
             free_all(sc);
             if (rc) return rc;
         }
+        {      // cs[n] = sum_k float(W16[n][k]) through the LayerNorm-folding helper with gamma = 1, beta = 0
+            std::vector<float> ones(D, 1.0f), zeros(D, 0.0f);
+            std::vector<void*> sc;
+            float *g1 = nullptr, *b0 = nullptr, *bf = nullptr;
+            half_t* wf = nullptr;
+            int r2 = upload_f32(c, sc, ones, &g1);
+            if (!r2) r2 = upload_f32(c, sc, zeros, &b0);
+            if (!r2) r2 = dev_alloc(c, sc, (size_t)128 * D * 2, (void**)&wf);
+            if (!r2) r2 = dev_alloc(c, sc, 128 * 4, (void**)&bf);
+            if (!r2) r2 = dev_alloc(c, own, 128 * 4, (void**)&a.down_cs);
+            if (!r2) {
+                hipError_t e = launch_fold_ln(a.down_w, g1, b0, a.down_b, wf, a.down_cs, bf, 128, D, 0);
+                if (e == hipSuccess) e = hipDeviceSynchronize();
+                if (e != hipSuccess) r2 = fail(c, HG_ERR_HIP, "down_proj row sums failed: %s", hipGetErrorString(e));
+            }
+            free_all(sc);
+            if (r2) return r2;
+        }
         keep_first(rc, as_f16(c, own, s.up_proj_weight, (size_t)D * d, &a.up_w, "adapter up_proj.weight"));
         keep_first(rc, as_f32(c, own, s.up_proj_bias, D, &a.up_b, "adapter up_proj.bias"));
         keep_first(rc, as_f32(c, own, s.scale, D, &a.scale, "adapter scale"));
         if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
-        rc = load_decoder_layer(c, own, s.prior_layer, d, a.dl[0]);
+        rc = load_decoder_layer(c, own, s.prior_layer, d, a.dl[0], a.w16[0]);
         if (rc) return rc;
-        rc = load_decoder_layer(c, own, s.self_layer, d, a.dl[1]);
+        rc = load_decoder_layer(c, own, s.self_layer, d, a.dl[1], a.w16[1]);
         if (rc) return rc;
         a.present = true;
     }
@@ -433,7 +464,9 @@ struct AdapterCall {
     bool enabled = false;
 };
 
-int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const AdapterCall& ac, hipStream_t s);
+// `fused`: LayerNorm folding is on - the stream's centred fp16 copy (c->h), its centre (c->muc) and the folding
+// statistics are current; the adapter consumes the copy and its up_proj re-emits all three for the updated stream
+int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const AdapterCall& ac, hipStream_t s, bool fused);
 
 // LayerNorm folded into the GEMMs: the residual GEMMs (out-proj, c_proj) also emit the fp16 copy of the updated
 // rows and per-row partial statistics; the consuming GEMMs (QKV, c_fc) read that copy and apply mean / rstd in
@@ -478,25 +511,41 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
     half_t* att = (half_t*)c->att.p;
     half_t* fc = (half_t*)c->fc.p;
     const bool adapters = ac && ac->enabled;
-    const bool fuse = ln_fold && !adapters && ln_fuse_ok(c, M, D);
+    // With adapters the folding survives when the adapter's up_proj can re-emit the fp16 copy and statistics
+    // (EPI_SCALE_RESID_LN_F32, duo kernel): HG_ADAPTER_FUSE=0 selects the separate path (fp32 -> fp16 copy of the stream
+    // per adapter, two LayerNorm kernels per block)
+    const char* af_e = getenv("HG_ADAPTER_FUSE");
+    const bool adapter_fuse_on = !(af_e && af_e[0] == '0');
+    bool fuse = ln_fold && ln_fuse_ok(c, M, D);
+    if (fuse && adapters) {
+        GemmArgs u{};
+        float dummy = 0.f;
+        u.out2 = (half_t*)&dummy; u.stats = &dummy; u.mu = &dummy; u.pos = &dummy; u.stats_ld = 4 * (D / 256);
+        u.M = M; u.N = D; u.ldc = D; u.K = 64; u.lda = 64;
+        fuse = adapter_fuse_on && gemm_duo_ok(EPI_SCALE_RESID_LN_F32, u);
+    }
     const int sld = 4 * (D / 256);
     float* mr = nullptr;
     float* mu = nullptr;
+    float* muc = nullptr;
     float* stats = nullptr;
     if (fuse) {
         int rc = ensure(c, c->mr, rup(M, 256) * 2 * 4);
         if (!rc) rc = ensure(c, c->mu, rup(M, 256) * 4);
         if (!rc) rc = ensure(c, c->stats, rup(M, 256) * (size_t)sld * 2 * 4);
         if (rc) return rc;
+        if (!rc && adapters) rc = ensure(c, c->muc, rup(M, 256) * 4);
+        if (rc) return rc;
         mr = (float*)c->mr.p;
         mu = (float*)c->mu.p;
+        muc = adapters ? (float*)c->muc.p : nullptr;
         stats = (float*)c->stats.p;
-        HG_HIP(launch_rowstats_cast(x, h, mr, mu, M, D, s));
+        HG_HIP(launch_rowstats_cast(x, h, mr, mu, M, D, s, muc));
     }
     for (size_t i = 0; i < blocks.size(); ++i) {
         const BlockW& b = blocks[i];
         if (adapters && c->vit.adapters.size() > i && c->vit.adapters[i].present) {
-            int rc = run_adapter(c, c->vit.adapters[i], n_seq, L, D, *ac, s);
+            int rc = run_adapter(c, c->vit.adapters[i], n_seq, L, D, *ac, s, fuse);
             if (rc) return rc;
         }
         const bool row0_last = row0_out && row0_env && !adapters && i + 1 == blocks.size();
@@ -549,7 +598,7 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         if (fuse) {
             g.out2 = h; g.stats = stats; g.stats_ld = sld; g.mu = mu;
             HG_HIP(gemm(c, EPI_RESID_LN_F32, g, s));
-            HG_HIP(launch_finalize_stats(stats, mr, mu, M, sld, 64, s));
+            HG_HIP(launch_finalize_stats(stats, mr, mu, M, sld, 64, s, muc));
         } else {
             HG_HIP(gemm(c, EPI_BIAS_RESID_F32, g, s));
         }
@@ -568,7 +617,7 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         if (fuse && i + 1 < blocks.size()) {      // the last block is followed by ln_post / ln_final on selected rows
             g.out2 = h; g.stats = stats; g.stats_ld = sld; g.mu = mu;
             HG_HIP(gemm(c, EPI_RESID_LN_F32, g, s));
-            HG_HIP(launch_finalize_stats(stats, mr, mu, M, sld, 64, s));
+            HG_HIP(launch_finalize_stats(stats, mr, mu, M, sld, 64, s, muc));
         } else {
             HG_HIP(gemm(c, EPI_BIAS_RESID_F32, g, s));
         }
@@ -588,7 +637,7 @@ int ensure_tower_ws(hg_ctx* c, int M, int D) {
     return rc;
 }
 
-int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const AdapterCall& ac, hipStream_t s) {
+int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const AdapterCall& ac, hipStream_t s, bool fused) {
     const int M = n_seq * L;
     float* x = (float*)c->x.p;
     half_t* h = (half_t*)c->h.p;
@@ -599,14 +648,21 @@ int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const Ada
     if (!rc) rc = ensure(c, c->adkv, (size_t)n_seq * Nmem * 64 * 4 * 2);
     if (rc) return rc;
     // down = relu(down_proj(x))  (CLIP_models_adapter_prior2.py:184-185)
-    HG_HIP(launch_f32_to_f16(x, h, (size_t)M * D, s));
     GemmArgs g{};
     g.A = h; g.lda = D; g.W = a.down_w; g.bias = a.down_b; g.out = c->ad32.p; g.ldc = 128; g.M = M; g.N = 128; g.K = D;
-    HG_HIP(gemm(c, EPI_BIAS_RELU_F32, g, s));
+    if (fused) {       // on the centred fp16 copy the residual GEMMs keep current: W (x16 + mu) + b
+        g.cs = a.down_cs; g.mu = (const float*)c->muc.p;
+        HG_HIP(gemm(c, EPI_MU_BIAS_RELU_F32, g, s));
+    } else {
+        HG_HIP(launch_f32_to_f16(x, h, (size_t)M * D, s));
+        HG_HIP(gemm(c, EPI_BIAS_RELU_F32, g, s));
+    }
     AdapterDev ad{};
     ad.down_w = a.down_w; ad.down_b = a.down_b; ad.up_w = a.up_w; ad.up_b = a.up_b; ad.scale = a.scale;
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < 2; ++k) {
         for (int j = 0; j < 12; ++j) ad.dl[k][j] = a.dl[k][j];
+        for (int j = 0; j < 6; ++j) ad.w16[k][j] = a.w16[k][j];
+    }
     // post-norm decoder layer over the 64-wide bottleneck (adapter...:186-200)
     HG_HIP(launch_adapter_decoder((const float*)c->ad32.p, ad, ac.priors, ac.mask, n_seq, L, ac.priors ? ac.N : 0,
                                   (float*)c->adkv.p, (half_t*)c->ad16.p, s));
@@ -614,7 +670,15 @@ int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const Ada
     g = GemmArgs{};
     g.A = (const half_t*)c->ad16.p; g.lda = 64; g.W = a.up_w; g.bias = a.up_b; g.pos = a.scale; g.out = x; g.ldc = D;
     g.M = M; g.N = D; g.K = 64;
-    HG_HIP(gemm(c, EPI_SCALE_RESID_F32, g, s));
+    if (fused) {       // ... and re-emit the fp16 copy + row statistics of the updated stream for the folded ln_1
+        const int sld = 4 * (D / 256);
+        g.out2 = h; g.stats = (float*)c->stats.p; g.stats_ld = sld; g.mu = (const float*)c->mu.p;
+        HG_HIP(gemm(c, EPI_SCALE_RESID_LN_F32, g, s));
+        HG_HIP(launch_finalize_stats((const float*)c->stats.p, (float*)c->mr.p, (float*)c->mu.p, M, sld, 64, s,
+                                     (float*)c->muc.p));
+    } else {
+        HG_HIP(gemm(c, EPI_SCALE_RESID_F32, g, s));
+    }
     return HG_OK;
 }
 
@@ -652,7 +716,7 @@ void hg_destroy(hg_ctx* c) {
     for (auto& m : c->mlp) free_all(m.owned);
     for (auto& m : c->cache) free_all(m.owned);
     Buf* bufs[] = {&c->x, &c->h, &c->qkv, &c->att, &c->fc, &c->head16, &c->tok32, &c->small, &c->i32,
-                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq};
+                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq};
     for (Buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
@@ -821,7 +885,7 @@ int hg_profile_end(hg_ctx* c, hg_prof_rec* recs, int max_recs, int32_t* n_recs) 
 int hg_workspace_bytes(hg_ctx* c, uint64_t* bytes) {
     if (!c || !bytes) return HG_ERR_INVALID;
     Buf* bufs[] = {&c->x, &c->h, &c->qkv, &c->att, &c->fc, &c->head16, &c->tok32, &c->small, &c->i32,
-                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq};
+                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq};
     uint64_t t = 0;
     for (Buf* b : bufs) t += b->bytes;
     *bytes = t;
@@ -1002,7 +1066,8 @@ static int to_host_f32(hg_ctx* c, const hg_tensor& t, size_t n, std::vector<floa
     return e == hipSuccess ? HG_OK : fail(c, HG_ERR_HIP, "hipMemcpy D2H failed for %s", name);
 }
 
-static int upload_f32(hg_ctx* c, std::vector<void*>& owned, const std::vector<float>& v, float** out) {
+namespace {
+int upload_f32(hg_ctx* c, std::vector<void*>& owned, const std::vector<float>& v, float** out) {
     void* p;
     int rc = dev_alloc(c, owned, v.size() * 4, &p);
     if (rc) return rc;
@@ -1010,6 +1075,7 @@ static int upload_f32(hg_ctx* c, std::vector<void*>& owned, const std::vector<fl
     *out = (float*)p;
     return HG_OK;
 }
+}  // namespace
 
 int hg_load_cache(hg_ctx* c, int slot, const hg_cache_weights* w) {
     if (!c || !w || slot < 0 || slot >= HG_MAX_CACHE_SLOTS) return HG_ERR_INVALID;

@@ -501,7 +501,8 @@ hipError_t launch_fold_ln(const half_t* w16, const float* gamma, const float* be
 }
 
 __global__ __launch_bounds__(256) void rowstats_cast_kernel(const float* __restrict__ x, half_t* __restrict__ x16,
-                                                            float* __restrict__ mr, float* __restrict__ mu, int M, int D) {
+                                                            float* __restrict__ mr, float* __restrict__ mu, int M, int D,
+                                                            float* __restrict__ muc) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= M) return;
@@ -538,19 +539,20 @@ __global__ __launch_bounds__(256) void rowstats_cast_kernel(const float* __restr
         mr[2 * (size_t)r] = 0.f;
         mr[2 * (size_t)r + 1] = rstd;
         mu[r] = mean;
+        if (muc) muc[r] = mean;
     }
 }
-hipError_t launch_rowstats_cast(const float* x, half_t* x16, float* mr, float* mu, int M, int D, hipStream_t s) {
+hipError_t launch_rowstats_cast(const float* x, half_t* x16, float* mr, float* mu, int M, int D, hipStream_t s, float* muc) {
     if (M <= 0) return hipSuccess;
     if (D % 4 || D > 256 * LN_MAXC) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(rowstats_cast_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, x16, mr, mu, M, D);
+    hipLaunchKernelGGL(rowstats_cast_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, x16, mr, mu, M, D, muc);
     return hipGetLastError();
 }
 
 // partial statistics of row m over nt column groups of `gw` columns each: (sum_k, M2_k = sum (x - mean_k)^2);
 // combined with Chan's parallel-variance formula (no E[x^2] - mean^2 cancellation)
 __global__ void finalize_stats_kernel(const float* __restrict__ stats, float* __restrict__ mr, float* __restrict__ mu,
-                                      int M, int nt, int gw) {
+                                      int M, int nt, int gw, float* __restrict__ muc) {
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
     const float* sp = stats + (size_t)m * nt * 2;
@@ -563,13 +565,15 @@ __global__ void finalize_stats_kernel(const float* __restrict__ stats, float* __
         const float d = sp[2 * t] / (float)gw - mean;
         m2 += sp[2 * t + 1] + (float)gw * d * d;
     }
-    mr[2 * (size_t)m] = mean - mu[m];             // the fp16 copy of this row was written as x - mu[m]
+    const float c = mu[m];
+    mr[2 * (size_t)m] = mean - c;                 // the fp16 copy of this row was written as x - mu[m]
     mr[2 * (size_t)m + 1] = 1.0f / sqrtf(m2 / D + 1e-5f);
+    if (muc) muc[m] = c;                          // centre of the current copy (adapter down_proj adds it back)
     mu[m] = mean;                                 // centre for the next residual GEMM's copy
 }
-hipError_t launch_finalize_stats(const float* stats, float* mr, float* mu, int M, int nt, int gw, hipStream_t s) {
+hipError_t launch_finalize_stats(const float* stats, float* mr, float* mu, int M, int nt, int gw, hipStream_t s, float* muc) {
     if (M <= 0) return hipSuccess;
-    hipLaunchKernelGGL(finalize_stats_kernel, dim3((M + 255) / 256), dim3(256), 0, s, stats, mr, mu, M, nt, gw);
+    hipLaunchKernelGGL(finalize_stats_kernel, dim3((M + 255) / 256), dim3(256), 0, s, stats, mr, mu, M, nt, gw, muc);
     return hipGetLastError();
 }
 

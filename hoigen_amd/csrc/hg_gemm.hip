@@ -33,6 +33,12 @@ __device__ __forceinline__ float quick_gelu(float v) {
 template <int EPI>
 __device__ __forceinline__ void epilogue(const GemmArgs& p, int m, int n, f32x4 v) {
     if (m >= p.M) return;
+    if constexpr (EPI == EPI_MU_BIAS_RELU_F32) {      // W (x16 + mu) + b = acc + mu * cs + b
+        const float mu = p.mu[m];
+        const f32x4 cs = *reinterpret_cast<const f32x4*>(p.cs + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaf(mu, cs[r], v[r]);
+    }
     if (p.bias) {
         const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
         v += b;
@@ -57,8 +63,8 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, int m, int n, f32x4 
         const f32x4 sc = *reinterpret_cast<const f32x4*>(p.pos + n);
         f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n);
         *dst = *dst + v * sc;
-    } else if constexpr (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_RELU_F32) {
-        if constexpr (EPI == EPI_BIAS_RELU_F32) {
+    } else if constexpr (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_RELU_F32 || EPI == EPI_MU_BIAS_RELU_F32) {
+        if constexpr (EPI == EPI_BIAS_RELU_F32 || EPI == EPI_MU_BIAS_RELU_F32) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
         }
@@ -216,6 +222,8 @@ hipError_t launch_gemm(int epi, const GemmArgs& a, hipStream_t s) {
     // two-workgroups-per-CU kernel (117 / 293 us against 147 / 305 us of the ring kernels at M = 50432); 2 = every
     // epilogue it implements except the LayerNorm-emitting residual (ring2 and duo tie there); 3 = that one as well
     static const int duo = []() { const char* e = getenv("HG_DUO"); return e ? atoi(e) : 1; }();
+    if (epi == EPI_SCALE_RESID_LN_F32) return gemm_duo_ok(epi, a) ? launch_gemm_duo(epi, a, s) : hipErrorInvalidValue;
+    if (epi == EPI_MU_BIAS_RELU_F32) return launch_gemm_simple(epi, a, s);
     const bool use_duo = duo >= 3 || (duo == 2 && epi != EPI_RESID_LN_F32) || (duo == 1 && epi == EPI_BIAS_RESID_F32);
     if (!force_simple && use_duo && gemm_duo_ok(epi, a)) return launch_gemm_duo(epi, a, s);
     const bool ln = (epi == EPI_LN_BIAS_F16 || epi == EPI_LN_BIAS_QGELU_F16 || epi == EPI_RESID_LN_F32);
@@ -236,6 +244,7 @@ hipError_t launch_gemm_simple(int epi, const GemmArgs& a, hipStream_t s) {
         case EPI_PATCH_F32: return launch_t<EPI_PATCH_F32>(a, s);
         case EPI_BIAS_RELU_F32: return launch_t<EPI_BIAS_RELU_F32>(a, s);
         case EPI_SCALE_RESID_F32: return launch_t<EPI_SCALE_RESID_F32>(a, s);
+        case EPI_MU_BIAS_RELU_F32: return (a.mu && a.cs) ? launch_t<EPI_MU_BIAS_RELU_F32>(a, s) : hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
 }

@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256, 2) void gemm_duo(const GemmArgs p, const int t
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BM = 128, BK = 64;
     constexpr int A_BYTES = 16384, W_BYTES = 32768;
-    constexpr bool RLN = (EPI == EPI_RESID_LN_F32);
+    constexpr bool SCALED = (EPI == EPI_SCALE_RESID_LN_F32);       // update multiplied by pos[n] (adapter up_proj)
+    constexpr bool RLN = (EPI == EPI_RESID_LN_F32 || SCALED);
     constexpr bool RESID = (EPI == EPI_BIAS_RESID_F32 || RLN);
     constexpr bool F16OUT = (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_BIAS_RELU_F16);
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [A 16 KiB][W0 32 KiB][W1 32 KiB]
@@ -259,20 +260,23 @@ __global__ __launch_bounds__(256, 2) void gemm_duo(const GemmArgs p, const int t
             // dead here, and a shallower pipeline exposes one HBM round trip per group (8 per tile: measured 53 k cycles
             // per tile against 13 k for the whole K loop of out_proj)
             constexpr int DEPTH = RLN ? 4 : 5;             // 5 spills with the LayerNorm extras (row sums, centres)
-            f32x4 xr[8][4], bvv[8];
+            f32x4 xr[8][4], bvv[8], scv[SCALED ? 8 : 1];
             const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
             auto fetch = [&](auto GG) {
                 constexpr int gg = decltype(GG)::value;
 #pragma unroll
                 for (int f = 0; f < 4; ++f) xr[gg][f] = *reinterpret_cast<const f32x4*>(xo + ro[f] + gg * 16);
                 bvv[gg] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nw + gg * 16) : z4;
+                if constexpr (SCALED) scv[gg] = *reinterpret_cast<const f32x4*>(p.pos + nw + gg * 16);
             };
             float sum[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
             auto consume = [&](auto GG) {
                 constexpr int gg = decltype(GG)::value;
 #pragma unroll
                 for (int f = 0; f < 4; ++f) {
-                    const f32x4 v = xr[gg][f] + (acc[f][gg] + bvv[gg]);
+                    f32x4 u = acc[f][gg] + bvv[gg];
+                    if constexpr (SCALED) u *= scv[gg];
+                    const f32x4 v = xr[gg][f] + u;
                     acc[f][gg] = v;
                     if (interior || mrow[f] < p.M) *reinterpret_cast<f32x4*>(xo + ro[f] + gg * 16) = v;
                     if constexpr (RLN) sum[f][gg >> 2] += (v[0] + v[1]) + (v[2] + v[3]);
@@ -467,8 +471,12 @@ static hipError_t launch_duo_t(const GemmArgs& a, hipStream_t s) {
 }
 
 bool gemm_duo_ok(int epi, const GemmArgs& a) {
-    if (!gemm_ring_ok(a)) return false;
-    if (epi == EPI_RESID_LN_F32) return a.out2 && a.stats && a.mu && a.stats_ld == 4 * (a.N / 256);
+    // as the ring kernels, but any K >= 64 (the K loop has no per-position specialisation)
+    if (a.N % 256 || a.K % 64 || a.K < 64 || a.M < 512 || a.N > 8192) return false;
+    const size_t Mp = (size_t)((a.M + 255) / 256) * 256;
+    if (Mp * a.lda * 2 >= (1ull << 31) || (size_t)a.N * a.K * 2 >= (1ull << 31)) return false;
+    if (epi == EPI_RESID_LN_F32 || epi == EPI_SCALE_RESID_LN_F32)
+        return a.out2 && a.stats && a.mu && a.stats_ld == 4 * (a.N / 256) && (epi == EPI_RESID_LN_F32 || a.pos);
     return epi == EPI_BIAS_F16 || epi == EPI_BIAS_QGELU_F16 || epi == EPI_BIAS_RELU_F16 || epi == EPI_BIAS_RESID_F32 ||
            epi == EPI_BIAS_F32 || epi == EPI_BIAS_RELU_F32 || epi == EPI_PATCH_F32;
 }
@@ -483,6 +491,7 @@ hipError_t launch_gemm_duo(int epi, const GemmArgs& a, hipStream_t s) {
         case EPI_BIAS_RELU_F32: return launch_duo_t<EPI_BIAS_RELU_F32>(a, s);
         case EPI_PATCH_F32: return launch_duo_t<EPI_PATCH_F32>(a, s);
         case EPI_RESID_LN_F32: return launch_duo_t<EPI_RESID_LN_F32>(a, s);
+        case EPI_SCALE_RESID_LN_F32: return launch_duo_t<EPI_SCALE_RESID_LN_F32>(a, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -24,7 +24,13 @@ enum Epilogue : int {
     EPI_LN_BIAS_QGELU_F16 = 9,
     // residual update that also emits what the next folded-LN GEMM needs (ring2 kernel only):
     //     out fp32 += acc + bias;  out2 fp16 = the updated rows;  stats[m][tile_n] = (sum, sum of squares) over the tile's columns
-    EPI_RESID_LN_F32 = 10
+    EPI_RESID_LN_F32 = 10,
+    // A = centred fp16 copy of the stream (x - mu[m]): out fp32 = relu(acc + mu[m] * cs[n] + bias[n]) = relu(W x + b)
+    // (adapter down_proj on the copy the residual GEMMs emit; simple kernel only)
+    EPI_MU_BIAS_RELU_F32 = 11,
+    // EPI_RESID_LN_F32 with the update scaled per column: out fp32 += (acc + bias) * pos[n]; fp16 copy + statistics
+    // (adapter up_proj: LayerNorm folding stays on behind the adapter; duo kernel only)
+    EPI_SCALE_RESID_LN_F32 = 12
 };
 
 struct GemmArgs {
@@ -123,11 +129,14 @@ hipError_t launch_copy_cols(const float* x, int ld, float* out, int R, int N, hi
 hipError_t launch_fold_ln(const half_t* w16, const float* gamma, const float* beta, const float* bias, half_t* wf16,
                           float* cs, float* bf, int N, int K, hipStream_t s);
 // x fp32 [M,D] -> centred fp16 copy x16 = fp16(x - mean), mu[m] = mean, mr[m] = (0, rstd) (eps 1e-5, biased variance)
-hipError_t launch_rowstats_cast(const float* x, half_t* x16, float* mr, float* mu, int M, int D, hipStream_t s);
+hipError_t launch_rowstats_cast(const float* x, half_t* x16, float* mr, float* mu, int M, int D, hipStream_t s,
+                                float* muc = nullptr);   // muc (optional): centre of the copy as well (= mu)
 // stats [M][nt][2]: per column group of gw columns (sum, sum of squared deviations from the group mean)
 // -> mr [M][2] = (mean - mu[m], rstd) over the nt * gw columns, eps 1e-5, then mu[m] = mean (the centre the next
 // residual GEMM subtracts from its fp16 copy)
-hipError_t launch_finalize_stats(const float* stats, float* mr, float* mu, int M, int nt, int gw, hipStream_t s);
+// muc (optional) receives the centre the CURRENT fp16 copy was written with (mu before this call)
+hipError_t launch_finalize_stats(const float* stats, float* mr, float* mu, int M, int nt, int gw, hipStream_t s,
+                                 float* muc = nullptr);
 
 #define HG_PRE_HDR 24   // header words per box in the pre-processing table (layout: hg_preproc.hip)
 // ---- crop pre-processing (hg_preproc.hip): head = per-box headers written by the host, tab receives the weight
@@ -153,6 +162,9 @@ struct AdapterDev {      // device pointers, all fp32 except the two MFMA operan
     // transposed to [in][out]:  0 WqT 1 WkT 2 WvT 3 bq 4 bk 5 bv 6 WoT 7 bo 8 {norm2.w,norm2.b,norm3.w,
     // norm3.b} 9 W1T [d][2d] 10 b1 11 {W2T [2d][d], b2}
     const float* dl[2][12];
+    // fp16 [out][in] copies for the MFMA decoder: 0 Wq 1 Wk 2 Wv [64,64] (rows of in_proj_weight), 3 Wo [64,64],
+    // 4 W1 [128,64], 5 W2 [64,128]; null -> the fp32 VALU kernel runs
+    const half_t* w16[2][6];
 };
 // down32 [M,128] fp32 (cols 0..63 = relu(down_proj(x))) -> out16 [M,64] fp16 (decoder layer output);
 // kv: scratch [B*Nmem, 2, 64] fp32 with Nmem = N (prior given) or L (prior == nullptr).

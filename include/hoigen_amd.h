@@ -228,14 +228,13 @@ int hg_workspace_bytes(hg_ctx*, uint64_t* bytes);
  * GEMM kinds are the epilogue classes: 0 bias->f16, 1 bias+QuickGELU->f16, 2 bias+ReLU->f16, 3 bias+residual f32,
  * 4 bias->f32, 5 patch embedding, 6 bias+ReLU->f32, 7 scale+residual, 8 LayerNorm-folded bias->f16 [QKV],
  * 9 LayerNorm-folded bias+QuickGELU->f16 [c_fc], 10 residual + fp16 copy + row statistics [out_proj, c_proj],
- * 11 the fused CoOp-VAE kernel (M rows; N, K = hidden sizes).  hg_profile_end synchronises and returns one record per
+ * 11 adapter down_proj on the centred copy, 12 adapter up_proj (scaled residual + fp16 copy + statistics).  hg_profile_end synchronises and returns one record per
  * timed launch, in launch order. */
 #define HG_PROF_OFF (-1)
 #define HG_PROF_ALL (-2)
 #define HG_PROF_ATTENTION 100 /* M = sequences, N = tokens per sequence, K = heads */
-#define HG_PROF_VAE 11
 typedef struct {
-    int32_t kind; /* GEMM epilogue class, HG_PROF_ATTENTION or HG_PROF_VAE */
+    int32_t kind; /* GEMM epilogue class or HG_PROF_ATTENTION */
     int32_t M, N, K;
     float ms;
 } hg_prof_rec;
