@@ -125,6 +125,35 @@ def clip_state_dict(cfg: dict = VIT_B16, seed: int = 0, ln_jitter: float = 0.1) 
     return sd
 
 
+def stress_clip_state_dict(cfg: dict = VIT_B16, seed: int = 0) -> "OrderedDict[str, np.ndarray]":
+    """``clip_state_dict`` with what trained CLIP checkpoints have and random init lacks (SURVEY.md §7 "hard parts"):
+    a few residual channels 50-100x larger than the rest, appearing both at the input of the towers and in the
+    middle of the network, and MLP hidden units whose pre-activations reach the hundreds (QuickGELU / fp16 range).
+    Deterministic; used by tests/golden/make_golden_stress.py (reference outputs) and the GPU test."""
+    sd = clip_state_dict(cfg, seed)
+    vw, tw = cfg["vision_width"], cfg["transformer_width"]
+    vch = [5 % vw, (vw // 6 + 2) % vw, (2 * vw // 3 + 5) % vw]            # 5, 130, 517 at width 768
+    tch = [7 % tw, (tw // 2 + 44) % tw, (tw - 3) % tw]
+    sd["visual.ln_pre.bias"][vch[0]] += 60.0                              # outlier from the first block on
+    sd["visual.ln_pre.weight"][vch[1]] *= 50.0                            # ... with a data-dependent sign / size
+    vl, tl = cfg["vision_layers"], cfg["transformer_layers"]
+    sd[f"visual.transformer.resblocks.{vl // 3}.mlp.c_proj.bias"][vch[2]] -= 80.0     # appears mid-network
+    sd[f"visual.transformer.resblocks.{vl // 2}.attn.out_proj.bias"][vch[0]] -= 30.0
+    for i in (0, vl // 2, vl - 1):                                        # hidden units with huge pre-activations
+        w = sd[f"visual.transformer.resblocks.{i}.mlp.c_fc.weight"]
+        w[11] *= 40.0
+        w[(4 * vw) // 2 + 3] *= -60.0
+        sd[f"visual.transformer.resblocks.{i}.mlp.c_fc.bias"][11] += 25.0
+    sd["positional_embedding"][:, tch[0]] += 2.0                          # text: no pre-LayerNorm, x = tok + pos ~ 0.03
+    sd["positional_embedding"][:, tch[1]] -= 3.0
+    sd[f"transformer.resblocks.{tl // 3}.mlp.c_proj.bias"][tch[2]] += 4.0
+    for i in (0, tl // 2, tl - 1):
+        w = sd[f"transformer.resblocks.{i}.mlp.c_fc.weight"]
+        w[13] *= 40.0
+        w[(4 * tw) // 2 + 1] *= -60.0
+    return sd
+
+
 # ---------------------------------------------------------------------------------------------
 # Adapter (variant C) parameters: /root/reference/CLIP_models_adapter_prior2.py:142-181
 # ---------------------------------------------------------------------------------------------

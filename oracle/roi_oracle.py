@@ -14,8 +14,11 @@ roi_align_common.h, unchanged since 0.7) is restated here:
     max(grid_h * grid_w, 1); samples at start + ph * bin + (iy + .5) * bin / grid;
   * bilinear interpolation with the boundary rule: outside [-1, H] x [-1, W] -> 0; coordinates <= 0 -> 0;
     low index >= size - 1 -> both indices = size - 1 (weight on it 1); float32 arithmetic.
-PARITY UNPINNED: no torchvision here to generate vectors from.  tests/test_roi_align.py anchors this restatement
-on analytic properties instead (constant and affine feature maps, for which bilinear sampling is exact).
+PARITY UNPINNED against the real library: no torchvision here to generate vectors from (and no network to get it).
+tests/test_roi_align.py anchors this restatement on (a) analytic properties (constant and affine feature maps, for
+which bilinear sampling is exact) and (b) hand-derived known-answer vectors (tests/golden/roi_known_answers.py) that
+separate the aligned=True half-pixel offset, the adaptive ceil(roi/P) sampling grid and the boundary rules from their
+alternatives.
 """
 import math
 

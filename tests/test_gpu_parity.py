@@ -288,6 +288,27 @@ def test_vitb16_offset_residual_stream_vs_oracle(monkeypatch):
     monkeypatch.delenv("HG_LN_FUSE")
 
 
+def test_vitb16_stress_outliers_vs_reference(g0, monkeypatch):
+    """SURVEY.md §7 hard part / VERDICT r1 item 8: residual channels 50-100x the rest (from the first block and from
+    the middle of the network) and c_fc pre-activations near 100, the way trained CLIP checkpoints behave.  Reference
+    outputs: tests/golden/make_golden_stress.py (fixture g8).  Both LayerNorm arrangements of the vision tower, text
+    with and without truncation."""
+    g = dict(np.load(f"{G}/g8_stress.npz"))
+    m = build_model(synth.to_torch(synth.stress_clip_state_dict(synth.VIT_B16, 0))).to(dev())
+    img = torch.from_numpy(synth.crops(4, 224, seed=1234)).to(dev())
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HG_LN_FUSE", mode)
+        out = m.visual.forward_trace(img)[0]
+        e = check(out, g["encode_image"], what=f"stress encode_image HG_LN_FUSE={mode}")
+        print(f"\nstress encode_image rel-L2 vs reference, HG_LN_FUSE={mode}: {e:.3e}")
+    monkeypatch.delenv("HG_LN_FUSE")
+    ids = ids_from_g0(g0, "hoi600", 64).to(dev())
+    for trunc in (True, False):
+        m.truncate_text = trunc
+        e = check(m.encode_text(ids), g["encode_text"], what=f"stress encode_text truncate={trunc}")
+        print(f"\nstress encode_text rel-L2 vs reference, truncate={trunc}: {e:.3e}")
+
+
 def test_vae_vs_oracle_ragged_rows():
     from oracle import clip_oracle as co, vae_oracle as vo
     d = dev()

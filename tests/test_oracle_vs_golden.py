@@ -195,3 +195,20 @@ def test_g5_prompt_learner_text(full_sd):
     prompts = vo.assemble_prompts(emb[:, :1], emb[:, 6:], ctx, torch.from_numpy(g5["bias"]), target)
     close(prompts[0], g5["prompts_row0"])
     close(co.text_encoder_embeds(full_sd, prompts, tok[target]), g5["text_features"], rel=1e-4)
+
+
+def test_g8_stress_outlier_channels():
+    """Outlier residual channels (x67 the median channel) and c_fc pre-activations ~ 90: the oracle against the
+    reference's own outputs (tests/golden/make_golden_stress.py).  The fixture records how hard the case is."""
+    g = dict(np.load(f"{G}/g8_stress.npz"))
+    rms = g["stream_channel_rms_block5"]
+    assert rms.max() / np.median(rms) > 50 and float(g["c_fc_preact_absmax_block0"]) > 60
+    sd = co.reference_weight_rounding(synth.stress_clip_state_dict(synth.VIT_B16, 0))
+    img = torch.from_numpy(synth.crops(2, 224, seed=1234)[:2])
+    close(co.encode_image(sd, img), g["encode_image"][:2], rel=1e-4)
+    g0 = json.load(open(f"{G}/g0_tokens.json"))
+    rows = g0["hoi600"]["ids"][:8]
+    ids = np.zeros((8, 77), np.int64)
+    for i, r in enumerate(rows):
+        ids[i, :len(r)] = r
+    close(co.encode_text(sd, torch.from_numpy(ids)), g["encode_text"][:8], rel=1e-4)

@@ -1,5 +1,7 @@
-"""RoI-align over the local feature map.  torchvision is not installed, so the oracle is anchored
-on analytic properties (parity unpinned, see oracle/roi_oracle.py); the HIP kernel is compared with the oracle."""
+"""RoI-align over the local feature map.  torchvision is not installed, so the oracle is anchored on
+analytic properties and on hand-derived known-answer vectors (tests/golden/roi_known_answers.py) that separate the
+aligned=True half-pixel offset, the adaptive ceil(roi/P) grid and the boundary rules from their alternatives - not on
+outputs of the real library (see oracle/roi_oracle.py); the HIP kernel is compared with both."""
 import os
 import sys
 
@@ -12,6 +14,18 @@ sys.path.insert(0, ROOT)
 from oracle import roi_oracle as ro  # noqa: E402
 
 SCALE = 14.0 / 224.0
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from roi_known_answers import cases as roi_cases  # noqa: E402
+
+
+def test_oracle_known_answers():
+    for feat, box, scale, P, want, what in roi_cases():
+        got = ro.roi_align(feat, np.array([box], np.float32), P, scale)[0]
+        assert np.abs(got - want).max() <= 1e-6, (what, got, want)
+    # the alternatives the vectors are meant to exclude really differ
+    feat, box, scale, P, want, _ = roi_cases()[0]
+    assert np.abs(ro.roi_align(feat, np.array([box], np.float32), P, scale, aligned=False)[0] - want).max() >= 2.0
+
 
 
 def affine_maps(H=14, W=14):
@@ -70,6 +84,10 @@ def test_hip_roi_align_vs_oracle():
     want_mean = want.reshape(44, 512, -1).mean(-1, dtype=np.float32)
     assert np.abs(mean.cpu().numpy() - want_mean).max() <= 1e-5
     assert roi_align(f, torch.zeros(0, 4, device=dev), 7, SCALE).shape == (0, 512, 7, 7)
+    # hand-derived known answers on the device (half-pixel offset, adaptive grid, boundary rules)
+    for feat_k, box, scale, P, want_k, what in roi_cases():
+        got_k = roi_align(torch.from_numpy(feat_k).to(dev), torch.tensor([box], dtype=torch.float32, device=dev), P, scale)
+        assert np.abs(got_k.cpu().numpy()[0] - want_k).max() <= 1e-6, what
     # analytic anchor on the device as well
     aff = torch.from_numpy(affine_maps()).to(dev)
     m = roi_align(aff, torch.tensor([[32., 48., 160., 200.]], device=dev), 7, SCALE, reduce_mean=True).cpu().numpy()[0]
