@@ -93,3 +93,50 @@ class CacheLogits:
                                             torch.cuda.current_stream().cuda_stream)
         _lib.check(self.device, rc, "hg_cache_logits")
         return out
+
+
+@torch.no_grad()
+def build_clip_cache_model(features: torch.Tensor, verbs, num_classes: int, num_shot: int):
+    """Cache keys / values with per-class shot selection: the part of ``utils.build_clip_cache_model``
+    (/root/reference/utils.py:31-61) that follows the encoder.
+
+    ``features [n, D]``: the L2-NORMALISED global embeddings of the n training crops in loader order (the reference
+    normalises ``feat_global`` row by row, :24-27, before this point); ``verbs``: for each crop the class indices
+    present in its target (``target['verb']`` / ``['actions']``, :33-38).  Returns ``(cache_keys [D, S],
+    cache_values [S, num_classes])`` with ``S = num_classes * num_shot`` for fully populated classes.
+
+    Same arithmetic and the same draws from torch's GLOBAL generator in the same order as the reference (one
+    ``torch.randperm(len)`` per class in class order, ``torch.randn(D)`` per missing shot of an empty class), so with
+    ``torch.manual_seed(s)`` set by the caller the result equals the reference's for the same inputs.  Pure index /
+    copy work on the host side of the device tensors; no kernels involved.
+    """
+    n, D = features.shape
+    dev = features.device
+    cache_keys = [[] for _ in range(num_classes)]
+    cache_values = [[] for _ in range(num_classes)]
+    for i in range(n):
+        values = torch.zeros(num_classes)
+        for j in verbs[i]:
+            values[int(j)] = 1
+        for k in torch.nonzero(values):                      # ascending class order, as torch.nonzero gives it
+            cache_values[k.item()].append(values)
+            cache_keys[k.item()].append(features[i, :])
+    new_keys, new_values = [], []
+    for c in range(num_classes):
+        ks, vs = [], []
+        topk_idx = torch.randperm(len(cache_values[c]))[:num_shot]
+        for idx in topk_idx:
+            vs.append(cache_values[c][idx])
+            ks.append(cache_keys[c][idx])
+        if not vs:                                           # class without samples: random keys, one-hot values (:52-57)
+            for _ in range(num_shot):
+                ks.append(torch.randn(D).to(dev))
+                v = torch.zeros(num_classes)
+                v[c] = 1
+                vs.append(v)
+        new_keys.append(torch.stack(ks))
+        new_values.append(torch.stack(vs))
+    keys = torch.cat(new_keys)
+    values = torch.cat(new_values)
+    keys = keys / keys.norm(dim=-1, keepdim=True)
+    return keys.permute(1, 0), values

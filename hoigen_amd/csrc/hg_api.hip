@@ -746,14 +746,15 @@ int hg_preprocess_crops(hg_ctx* c, const uint8_t* img, int H, int W, const int32
         const int cw = bx[2] - bx[0], ch = bx[3] - bx[1];
         if (cw <= 0 || ch <= 0) return fail(c, HG_ERR_INVALID, "hg_preprocess_crops: empty box %d", b);
         int sw = cw, sh = ch, px = 0, py = 0;
-        if (pad_square && cw != ch) {                       // expand2square: centred, floor((side - short) / 2)
+        if ((pad_square & HG_PRE_PAD_SQUARE) && cw != ch) {                       // expand2square: centred, floor((side - short) / 2)
             if (cw > ch) py = (cw - ch) / 2; else px = (ch - cw) / 2;
             sw = sh = cw > ch ? cw : ch;
         }
         // torchvision Resize: short side -> n_px, long side -> int(n_px * long / short); CenterCrop offsets
         // int(round(d / 2.0)) with Python's round-half-to-even
         int nw, nh;
-        if (sw <= sh) { nw = n_px; nh = (int)((double)((long long)n_px * sh) / (double)sw); }
+        if (pad_square & HG_PRE_STRETCH) { nw = nh = n_px; }        // IResize([n_px, n_px]): both sides, no centre crop
+        else if (sw <= sh) { nw = n_px; nh = (int)((double)((long long)n_px * sh) / (double)sw); }
         else { nw = (int)((double)((long long)n_px * sw) / (double)sh); nh = n_px; }
         const int left = (int)nearbyint((double)(nw - n_px) / 2.0), top = (int)nearbyint((double)(nh - n_px) / 2.0);
         auto taps = [](int in, int outn) {
@@ -792,7 +793,8 @@ int hg_preprocess_crops(hg_ctx* c, const uint8_t* img, int H, int W, const int32
     int32_t* tab = tab_off + n;
     HG_HIP(hipMemcpyAsync(head_d, head.data(), head.size() * 4, hipMemcpyHostToDevice, s));
     HG_HIP(hipStreamSynchronize(s));      // `head` is a stack-lifetime host buffer
-    HG_HIP(launch_preprocess(img, H, W, head_d, tab, tab_off, n, n_px, max_rows, (uint8_t*)c->pre.p, out, out_u8, s));
+    HG_HIP(launch_preprocess(img, H, W, head_d, tab, tab_off, n, n_px, max_rows, (uint8_t*)c->pre.p, out, out_u8, s,
+                             (pad_square & HG_PRE_IMAGENET_NORM) != 0));
     return HG_OK;
 }
 

@@ -50,7 +50,7 @@ namespace hg {
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_duo(const GemmArgs p, const int tiles_n, const int n_tiles,
-                                                   const unsigned a_bytes, const int gsz) {
+                                                   const unsigned a_bytes, const int gsz, const int xm) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BM = 128, BK = 64;
     constexpr int A_BYTES = 16384, W_BYTES = 32768;
@@ -89,6 +89,11 @@ __global__ __launch_bounds__(256, 2) void gemm_duo(const GemmArgs p, const int t
     };
     if (my_tiles <= 0) return;
     const int S = my_tiles * nk;                                   // K-tiles in this workgroup's stream
+#ifdef HG_EXPERIMENTS
+    const int xmode = xm;        // timing experiments (wrong results): 1 every tile streams A tile 0, 2 epilogue on tile 0's rows
+#else
+    constexpr int xmode = 0;
+#endif
 
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW =
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo(const GemmArgs p, const int t
     {
         int tm, tn;
         tile_of(slot, tm, tn);
-        lA.org = tm * BM * p.lda * 2;
+        lA.org = (xmode & 1) ? 0 : tm * BM * p.lda * 2;
         lW.org = tn * 256 * p.K * 2;
     }
     auto ld_advance = [&](Ld& l, bool isA) {
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo(const GemmArgs p, const int t
             if (l.r < my_tiles) {
                 int tm, tn;
                 tile_of(slot + l.r * cpx, tm, tn);
-                l.org = isA ? tm * BM * p.lda * 2 : tn * 256 * p.K * 2;
+                l.org = isA ? ((xmode & 1) ? 0 : tm * BM * p.lda * 2) : tn * 256 * p.K * 2;
             }
         }
     };
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo(const GemmArgs p, const int t
     for (int r = 0; r < my_tiles; ++r) {
         int tm, tn;
         tile_of(slot + r * cpx, tm, tn);
-        const int m0 = tm * BM, n0 = tn * 256;
+        const int m0 = (xmode & 2) ? 0 : tm * BM, n0 = tn * 256;
 #pragma unroll
         for (int f = 0; f < 4; ++f)
 #pragma unroll
@@ -436,6 +441,7 @@ static hipError_t launch_duo_t(const GemmArgs& a, hipStream_t s) {
         gsz = (tiles_n + ngroups - 1) / ngroups;
     }
     // timing experiments: HG_DUO_LDS_CUT = bytes requested less (results wrong), HG_DUO_GRID = workgroups per CU
+    static const int xm_env = []() { const char* e = getenv("HG_DUO_XMODE"); return e ? atoi(e) : 0; }();
     static const int lds_cut = []() { const char* e = getenv("HG_DUO_LDS_CUT"); return e ? atoi(e) : 0; }();
     static const int per_cu = []() { const char* e = getenv("HG_DUO_GRID"); return e ? atoi(e) : 2; }();
     const int grid2 = n_tiles < per_cu * n_cu ? n_tiles : per_cu * n_cu;
@@ -447,7 +453,7 @@ static hipError_t launch_duo_t(const GemmArgs& a, hipStream_t s) {
         hipMemsetAsync(d, 0, n * 8, s);
         GemmArgs b = a;
         b.dbg = d;
-        hipLaunchKernelGGL((gemm_duo<EPI>), dim3(grid2), dim3(256), LDS - lds_cut, s, b, tiles_n, n_tiles, (unsigned)a_bytes, gsz);
+        hipLaunchKernelGGL((gemm_duo<EPI>), dim3(grid2), dim3(256), LDS - lds_cut, s, b, tiles_n, n_tiles, (unsigned)a_bytes, gsz, xm_env);
         hipStreamSynchronize(s);
         unsigned long long* h = (unsigned long long*)malloc(n * 8);
         hipMemcpy(h, d, n * 8, hipMemcpyDeviceToHost);
@@ -466,7 +472,7 @@ static hipError_t launch_duo_t(const GemmArgs& a, hipStream_t s) {
         return hipGetLastError();
     }
 #endif
-    hipLaunchKernelGGL((gemm_duo<EPI>), dim3(grid2), dim3(256), LDS - lds_cut, s, a, tiles_n, n_tiles, (unsigned)a_bytes, gsz);
+    hipLaunchKernelGGL((gemm_duo<EPI>), dim3(grid2), dim3(256), LDS - lds_cut, s, a, tiles_n, n_tiles, (unsigned)a_bytes, gsz, xm_env);
     return hipGetLastError();
 }
 

@@ -144,7 +144,7 @@ hipError_t launch_finalize_stats(const float* stats, float* mr, float* mu, int M
 // [n,n_px,n_px,3] before normalisation
 hipError_t launch_preprocess(const uint8_t* img, int H, int W, const int32_t* head, int32_t* tab,
                              const int32_t* tab_off, int n, int n_px, int max_rows, uint8_t* tmp, float* out,
-                             uint8_t* out_u8, hipStream_t s);
+                             uint8_t* out_u8, hipStream_t s, bool imagenet_norm = false);
 
 // RoI-align (torchvision semantics, aligned=True, sampling_ratio=-1) of feat [C,H,W] for boxes [n,4] (device):
 // out_pooled [n,C,P,P] and/or out_mean [n,C] (= .flatten(2).mean(-1)); either may be null

@@ -152,13 +152,17 @@ __global__ __launch_bounds__(256) void preproc_v_kernel(const int32_t* __restric
 
 hipError_t launch_preprocess(const uint8_t* img, int H, int W, const int32_t* head, int32_t* tab,
                              const int32_t* tab_off, int n, int n_px, int max_rows, uint8_t* tmp, float* out,
-                             uint8_t* out_u8, hipStream_t s) {
+                             uint8_t* out_u8, hipStream_t s, bool imagenet_norm) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(preproc_tables_kernel, dim3(n, 2), dim3(256), 0, s, head, tab, tab_off, n_px);
     if (max_rows > 0)
         hipLaunchKernelGGL(preproc_h_kernel, dim3(max_rows, n), dim3(256), 0, s, img, H, W, head, tab, tab_off, n_px, tmp);
-    hipLaunchKernelGGL(preproc_v_kernel, dim3(n_px, n), dim3(256), 0, s, head, tab, tab_off, n_px, tmp, out, out_u8,
-                       0.48145466f, 0.4578275f, 0.40821073f, 0.26862954f, 0.26130258f, 0.27577711f);
+    if (imagenet_norm)      // the detector's CLIP view: utils_tip_cache_and_union_finetune.py:86-89
+        hipLaunchKernelGGL(preproc_v_kernel, dim3(n_px, n), dim3(256), 0, s, head, tab, tab_off, n_px, tmp, out, out_u8,
+                           0.485f, 0.456f, 0.406f, 0.229f, 0.224f, 0.225f);
+    else                    // CLIP's own constants: clipnet/clip.py:81
+        hipLaunchKernelGGL(preproc_v_kernel, dim3(n_px, n), dim3(256), 0, s, head, tab, tab_off, n_px, tmp, out, out_u8,
+                           0.48145466f, 0.4578275f, 0.40821073f, 0.26862954f, 0.26130258f, 0.27577711f);
     return hipGetLastError();
 }
 

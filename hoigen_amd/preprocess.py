@@ -27,8 +27,13 @@ class CropPreprocessor:
     ``background`` before the resize.  ``return_u8=True`` also returns the resized uint8 crops [n, n_px, n_px, 3].
     """
 
-    def __init__(self, n_px: int = 224, pad_square: bool = False, background: Sequence[int] = (0, 0, 0)):
+    def __init__(self, n_px: int = 224, pad_square: bool = False, background: Sequence[int] = (0, 0, 0),
+                 stretch: bool = False, imagenet_norm: bool = False):
+        """``stretch``: ``IResize([n_px, n_px])`` of the detector's CLIP view (both sides to n_px, no centre crop;
+        detr/datasets/transforms_clip.py:279-288); ``imagenet_norm``: ImageNet mean/std
+        (utils_tip_cache_and_union_finetune.py:86-89) instead of CLIP's (clipnet/clip.py:81)."""
         self.n_px, self.pad_square, self.background = int(n_px), bool(pad_square), tuple(background)
+        self.flags = (1 if pad_square else 0) | (2 if stretch else 0) | (4 if imagenet_norm else 0)
 
     def __call__(self, image_u8: torch.Tensor, boxes, return_u8: bool = False):
         if not isinstance(image_u8, torch.Tensor) or image_u8.dtype != torch.uint8 or image_u8.dim() != 3 \
@@ -52,7 +57,7 @@ class CropPreprocessor:
             idx = dev.index if dev.index is not None else torch.cuda.current_device()
             with torch.cuda.device(dev):
                 rc = _lib.lib().hg_preprocess_crops(_lib.ctx(idx), img.data_ptr(), img.shape[0], img.shape[1],
-                                                    bx.ctypes.data, n, npx, int(self.pad_square), bg,
+                                                    bx.ctypes.data, n, npx, self.flags, bg,
                                                     out.data_ptr(), u8.data_ptr() if return_u8 else None,
                                                     torch.cuda.current_stream().cuda_stream)
             _lib.check(idx, rc, "hg_preprocess_crops")

@@ -213,7 +213,14 @@ int hg_cache_logits(hg_ctx*, int slot, const float* feats, int R, float* out, vo
  * with Pillow's 8-bit resampling arithmetic (bit-exact uint8).  img: uint8 [H,W,3] RGB on the device;
  * boxes_host: int32 [n][4] = (x0, y0, x1, y1) in HOST memory (PIL convention, may leave the image);
  * background: 0x00BBGGRR; out: fp32 [n,3,n_px,n_px] (device); out_u8: optional uint8 [n,n_px,n_px,3] (device),
- * the resized crops before normalisation. */
+ * the resized crops before normalisation.
+ * `pad_square` is a set of flags: HG_PRE_PAD_SQUARE (expand2square first), HG_PRE_STRETCH (the detector's CLIP view,
+ * IResize([n_px, n_px]): both sides are resized to n_px, no centre crop; detr/datasets/transforms_clip.py:139-171,
+ * :279-288), HG_PRE_IMAGENET_NORM (Normalize with the ImageNet constants of utils_tip_cache_and_union_finetune.py:86-89
+ * instead of CLIP's). */
+#define HG_PRE_PAD_SQUARE 1
+#define HG_PRE_STRETCH 2
+#define HG_PRE_IMAGENET_NORM 4
 int hg_preprocess_crops(hg_ctx*, const uint8_t* img, int H, int W, const int32_t* boxes_host, int n, int n_px,
                         int pad_square, uint32_t background, float* out, uint8_t* out_u8, void* stream);
 /* vae_loss forward value (main_coop_vae.py:300-303) -> loss[1] fp32. */

@@ -153,13 +153,25 @@ def normalize(u8: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(x.transpose(2, 0, 1))
 
 
-def preprocess_boxes(img: np.ndarray, boxes, n_px: int = 224, pad_square: bool = False, background=(0, 0, 0)):
-    """image uint8 [H, W, 3] + boxes [n, 4] -> (uint8 [n, n_px, n_px, 3], float32 [n, 3, n_px, n_px])."""
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def preprocess_boxes(img: np.ndarray, boxes, n_px: int = 224, pad_square: bool = False, background=(0, 0, 0),
+                     stretch: bool = False, imagenet_norm: bool = False):
+    """image uint8 [H, W, 3] + boxes [n, 4] -> (uint8 [n, n_px, n_px, 3], float32 [n, 3, n_px, n_px]).
+    ``stretch``: the detector's CLIP view, ``IResize([n_px, n_px])`` = ``F.resize(img, (n_px, n_px), BICUBIC)``
+    (detr/datasets/transforms_clip.py:139-171, :279-288), no centre crop; ``imagenet_norm``: the constants of
+    utils_tip_cache_and_union_finetune.py:86-89."""
     u8 = []
     for b in boxes:
         c = crop_box(img, b)
         if pad_square:
             c = expand2square(c, background)
-        u8.append(clip_transform_u8(c, n_px))
+        u8.append(resize_bicubic(c, n_px, n_px) if stretch else clip_transform_u8(c, n_px))
     u8 = np.stack(u8)
+    if imagenet_norm:
+        m, sd = np.asarray(IMAGENET_MEAN, np.float32), np.asarray(IMAGENET_STD, np.float32)
+        fl = [np.ascontiguousarray(((u.astype(np.float32) / np.float32(255.0) - m) / sd).transpose(2, 0, 1)) for u in u8]
+        return u8, np.stack(fl)
     return u8, np.stack([normalize(u) for u in u8])

@@ -65,6 +65,14 @@ def main():
         out[f"boxes{ci}"] = boxes
         out[f"u8_{ci}"] = u8
         out[f"u8_sq_{ci}"] = u8_sq
+    # the detector's CLIP view: IResize([224, 224]) of the whole image and of one box, Pillow's resize to both sides
+    for ci in range(len(cases)):
+        pil = Image.fromarray(out[f"img{ci}"])
+        W, H = pil.size
+        bs = [(0, 0, W, H), tuple(int(v) for v in out[f"boxes{ci}"][0])]
+        out[f"stretch_boxes{ci}"] = np.asarray(bs, np.int32)
+        out[f"stretch_u8_{ci}"] = np.stack([np.asarray(pil.crop(b).resize((224, 224), Image.BICUBIC).convert("RGB"), np.uint8)
+                                           for b in bs])
     # normalised float output for one case (ToTensor + Normalize)
     x = out["u8_0"].astype(np.float32) / np.float32(255.0)
     out["norm_0"] = np.ascontiguousarray(((x - MEAN) / STD).transpose(0, 3, 1, 2))

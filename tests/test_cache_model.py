@@ -83,3 +83,24 @@ def test_hip_cache_logits_ragged_and_update():
     assert rel(m(torch.from_numpy(f).to(dev)).cpu().numpy(), co.cache_logits(f, w2, b, lab, lens))[0] <= TOL
     with pytest.raises(ValueError):
         m(torch.zeros(3, K + 64, device=dev))
+
+
+def test_cache_key_build_matches_reference_shot_selection():
+    """utils.build_clip_cache_model (reference utils.py:6-61, executed by tests/golden/make_golden_cache_keys.py) vs
+    hoigen_amd.cache_model.build_clip_cache_model on the same features / targets / torch seed: which samples are
+    kept per class (randperm order), the random keys of empty classes, normalisation and layout.  Host logic, CPU."""
+    from hoigen_amd.cache_model import build_clip_cache_model
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "g9_cache_keys.npz")))
+    feats = torch.from_numpy(g["features"])
+    feats = torch.stack([f / f.norm(dim=-1, keepdim=True) for f in feats])           # utils.py:24-27
+    verbs = [[int(v) for v in row if v >= 0] for row in g["verbs"]]
+    torch.manual_seed(int(g["seed"]))
+    keys, values = build_clip_cache_model(feats, verbs, int(g["num_classes"]), int(g["num_shot"]))
+    assert keys.shape == g["cache_keys"].shape and values.shape == g["cache_values"].shape
+    assert np.array_equal(values.numpy(), g["cache_values"])                          # labels: exact
+    assert np.abs(keys.numpy() - g["cache_keys"]).max() <= 1e-7                       # same samples, same order
+    # every kept key is one of the (normalised) input rows or a random key of an empty class
+    kept = keys.t().numpy()
+    d = np.abs(kept[:, None, :] - feats.numpy()[None, :, :]).max(-1).min(-1)
+    empty = [c for c in range(int(g["num_classes"])) if not any(c in v for v in verbs)]
+    assert (d > 1e-6).sum() == len(empty) * int(g["num_shot"])

@@ -28,6 +28,11 @@ def test_oracle_matches_pillow_goldens(g6):
         assert np.array_equal(u8s, g6[f"u8_sq_{ci}"])
         if ci == 0:
             assert np.array_equal(nrm, g6["norm_0"])
+        # the detector's CLIP view: IResize([224, 224]) = resize of both sides, no centre crop
+        u8r, nrm_r = po.preprocess_boxes(g6[f"img{ci}"], g6[f"stretch_boxes{ci}"], stretch=True, imagenet_norm=True)
+        assert np.array_equal(u8r, g6[f"stretch_u8_{ci}"])
+        want = (g6[f"stretch_u8_{ci}"].astype(np.float32) / 255.0 - np.float32([0.485, 0.456, 0.406])) / np.float32([0.229, 0.224, 0.225])
+        assert np.abs(nrm_r - want.transpose(0, 3, 1, 2)).max() <= 1e-6
 
 
 def test_facade_errors_without_gpu():
@@ -50,6 +55,12 @@ def test_hip_preprocess_bit_exact_vs_pillow_goldens(g6):
             assert np.abs(out.cpu().numpy() - g6["norm_0"]).max() <= 1e-6
         _, u8s = preprocess.CropPreprocessor(224, pad_square=True)(img, g6[f"boxes{ci}"][:2], return_u8=True)
         assert np.array_equal(u8s.cpu().numpy(), g6[f"u8_sq_{ci}"])
+        # IResize([224, 224]) + ImageNet normalisation (the detector's CLIP view, utils_tip...:86-89,105-114)
+        pre = preprocess.CropPreprocessor(224, stretch=True, imagenet_norm=True)
+        outr, u8r = pre(img, g6[f"stretch_boxes{ci}"], return_u8=True)
+        assert np.array_equal(u8r.cpu().numpy(), g6[f"stretch_u8_{ci}"])
+        _, want = po.preprocess_boxes(g6[f"img{ci}"], g6[f"stretch_boxes{ci}"], stretch=True, imagenet_norm=True)
+        assert np.abs(outr.cpu().numpy() - want).max() <= 1e-6
     img0 = torch.from_numpy(g6["img0"]).to(dev)
     assert preprocess.CropPreprocessor()(img0, np.zeros((0, 4), np.int32)).shape == (0, 3, 224, 224)
     with pytest.raises(ValueError):
@@ -79,3 +90,32 @@ def test_hip_preprocess_vs_oracle_random_boxes_and_pipeline():
     m = build_model(synth.to_torch(synth.clip_state_dict(synth.VIT_B16, 0))).to(dev)
     emb = m.encode_image(out)
     assert emb.shape == (15, 512) and torch.isfinite(emb).all()
+
+
+@pytest.mark.gpu
+def test_record_emission_vs_oracle_chain():
+    """hoigen_amd.records.emit_record (the producer of the entries upt...:636-688 reads): union / object / human crops of
+    every pair -> Pillow-exact pre-processing -> encode_image, against the oracle chain on the same boxes."""
+    from hoigen_amd import records, synth
+    from hoigen_amd.model import build_model
+    from oracle import clip_oracle as co
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(11)
+    img = rng.randint(0, 256, size=(240, 320, 3)).astype(np.uint8)
+    bh = np.array([[20.4, 30.6, 120.5, 200.2], [150, 10, 300, 230]], np.float32)
+    bo = np.array([[100.0, 90.0, 210.7, 160.1], [140, 120, 200, 180]], np.float32)
+    sd_np = synth.clip_state_dict(synth.VIT_B16, 0)
+    m = build_model(synth.to_torch(sd_np)).float().to(dev)
+    rec = records.emit_record(m, torch.from_numpy(img).to(dev), bh, bo, verbs=[3, 57], objects=[1, 40])
+    assert sorted(rec) == ["boxes_h", "boxes_o", "huamn_features", "object_features", "objects", "union_features", "verbs"]
+    assert rec["union_features"].shape == (2, 512) and rec["verbs"].tolist() == [3, 57]
+    ub = records.union_boxes(bh, bo)
+    assert np.allclose(ub, [[20.4, 30.6, 210.7, 200.2], [140, 10, 300, 230]])
+    sd = co.reference_weight_rounding(sd_np)
+    for key, boxes in (("union_features", ub), ("object_features", bo), ("huamn_features", bh)):
+        _, x = po.preprocess_boxes(img, records.pil_box(boxes))
+        want = co.encode_image(sd, torch.from_numpy(x)).numpy()
+        err = np.linalg.norm(rec[key] - want, axis=1) / np.linalg.norm(want, axis=1)
+        assert err.max() <= 1e-3, (key, err)
+    empty = records.emit_record(m, torch.from_numpy(img).to(dev), np.zeros((0, 4)), np.zeros((0, 4)), [], [])
+    assert empty["union_features"].shape == (0, 512)
