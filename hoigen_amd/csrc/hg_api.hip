@@ -818,7 +818,6 @@ int hg_test_gemm(hg_ctx* c, const float* a, const float* w, const float* bias, f
     if (kernel == 1) e = launch_gemm_simple(epi, g, s);
     else if (kernel == 2) e = gemm_ring_ok(g) ? launch_gemm_ring(epi, g, s) : hipErrorInvalidValue;
     else if (kernel == 3) e = gemm_duo_ok(epi, g) ? launch_gemm_duo(epi, g, s) : hipErrorInvalidValue;
-    else if (kernel == 4) e = gemm_w16_ok(epi, g) ? launch_gemm_w16(epi, g, s) : hipErrorInvalidValue;
     else e = launch_gemm(epi, g, s);
     ps.finish();
     if (e != hipSuccess) return fail(c, HG_ERR_HIP, "test gemm launch failed: %s", hipGetErrorString(e));

@@ -72,9 +72,6 @@ hipError_t launch_gemm_simple(int epi, const GemmArgs& a, hipStream_t s);
 // two 4-wave workgroups per CU, 128x256 tiles, free-running (hg_gemm_duo.hip): residual GEMMs and fp16/fp32 outputs
 bool gemm_duo_ok(int epi, const GemmArgs& a);
 hipError_t launch_gemm_duo(int epi, const GemmArgs& a, hipStream_t s);
-// 16 waves per workgroup (four per SIMD), 256x256 tiles (hg_gemm_w16.hip): occupancy experiment
-bool gemm_w16_ok(int epi, const GemmArgs& a);
-hipError_t launch_gemm_w16(int epi, const GemmArgs& a, hipStream_t s);
 
 // ---- attention: softmax(Q K^T / sqrt(64) [+causal]) V, head_dim 64 --------------------------
 // qkv fp16 [n_seq*L, 3*D] rows = tokens (q|k|v column blocks, head h = 64h..64h+63);
