@@ -45,7 +45,8 @@ class hg_adapter_weights(C.Structure):
     _fields_ = [("present", C.c_int32), ("bottleneck", C.c_int32), ("scale", hg_tensor),
                 ("down_proj_weight", hg_tensor), ("down_proj_bias", hg_tensor),
                 ("up_proj_weight", hg_tensor), ("up_proj_bias", hg_tensor),
-                ("prior_layer", hg_decoder_layer_weights), ("self_layer", hg_decoder_layer_weights)]
+                ("prior_layer", hg_decoder_layer_weights), ("self_layer", hg_decoder_layer_weights),
+                ("n_extra_prior_layers", C.c_int32), ("extra_prior_layers", C.POINTER(hg_decoder_layer_weights))]
 
 
 class hg_vit_weights(C.Structure):

@@ -287,7 +287,7 @@ __device__ __forceinline__ int key_slot(int key) {
 template <bool SELF>
 __global__ __launch_bounds__(256) void adapter_decoder_mfma(const float* __restrict__ down, int ld_down, DecW16 W,
                                                             const float* __restrict__ priors, const uint8_t* __restrict__ mask,
-                                                            int L, int N, half_t* __restrict__ out16) {
+                                                            int L, int N, half_t* __restrict__ out16, float* chain32) {
     extern __shared__ __attribute__((aligned(16))) char smem_ad[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -459,6 +459,16 @@ __global__ __launch_bounds__(256) void adapter_decoder_mfma(const float* __restr
 #pragma unroll
         for (int g = 0; g < 4; ++g) tgt[f][g] += t[f][g];
     layer_norm_T(tgt, W.norms + 128, W.norms + 192, lane);
+    if (chain32) {      // adapter_num_layers > 1: fp32, in the layout the next layer of the chain reads (rows of ld_down)
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+            if (tok[f] < L) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(chain32 + ((size_t)seq * L + tok[f]) * ld_down + 16 * g + 4 * q) = tgt[f][g];
+            }
+        return;
+    }
 #pragma unroll
     for (int f = 0; f < 4; ++f)
         if (tok[f] < L) {
@@ -476,7 +486,7 @@ __global__ __launch_bounds__(256) void adapter_decoder_mfma(const float* __restr
 // down32 [M,128] fp32 (cols 0..63 = relu(down_proj(x))) -> out16 [M,64] fp16 = decoder layer output
 hipError_t launch_adapter_decoder(const float* down32, const AdapterDev& ad, const float* priors,
                                   const uint8_t* mask, int B, int L, int N, float* kv, half_t* out16,
-                                  hipStream_t s) {
+                                  hipStream_t s, float* chain32) {
     const int which = priors ? 0 : 1;            // mhsa_layers.0 (prior) vs mhsa (self)
     const float* const* dl = ad.dl[which];
     const int Nmem = priors ? N : L;
@@ -499,11 +509,12 @@ hipError_t launch_adapter_decoder(const float* down32, const AdapterDev& ad, con
             attr_set = true;
         }
         if (priors)
-            hipLaunchKernelGGL((adapter_decoder_mfma<false>), dim3(B), dim3(256), lds, s, down32, 128, Wd, priors, mask, L, N, out16);
+            hipLaunchKernelGGL((adapter_decoder_mfma<false>), dim3(B), dim3(256), lds, s, down32, 128, Wd, priors, mask, L, N, out16, chain32);
         else
-            hipLaunchKernelGGL((adapter_decoder_mfma<true>), dim3(B), dim3(256), lds, s, down32, 128, Wd, priors, mask, L, L, out16);
+            hipLaunchKernelGGL((adapter_decoder_mfma<true>), dim3(B), dim3(256), lds, s, down32, 128, Wd, priors, mask, L, L, out16, chain32);
         return hipGetLastError();
     }
+    if (chain32) return hipErrorInvalidValue;      // chained layers exist only on the MFMA path
     hipLaunchKernelGGL(adapter_kv_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, s, priors ? priors : down32,
                        priors ? AD : 128, n_rows, dl[1], dl[4], dl[2], dl[5], kv);
     DecoderPtrs P{dl[0], dl[3], dl[6], dl[7], dl[8], dl[9], dl[10], dl[11]};

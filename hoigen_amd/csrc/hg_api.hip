@@ -50,6 +50,8 @@ struct AdapterW {
     float* scale = nullptr;
     float* dl[2][12] = {};     // see AdapterDev
     half_t* w16[2][6] = {};    // see AdapterDev
+    struct Extra { float* dl[12] = {}; half_t* w16[6] = {}; };
+    std::vector<Extra> extra;  // mhsa_layers.1 .. N-1 (adapter_num_layers > 1), prior path only
 };
 
 struct Vit {
@@ -419,6 +421,13 @@ int load_adapters(hg_ctx* c, const hg_adapter_weights* src, int layers) {
         if (rc) return rc;
         rc = load_decoder_layer(c, own, s.self_layer, d, a.dl[1], a.w16[1]);
         if (rc) return rc;
+        if (s.n_extra_prior_layers < 0 || (s.n_extra_prior_layers > 0 && !s.extra_prior_layers))
+            return fail(c, HG_ERR_INVALID, "adapter %d: bad extra_prior_layers", i);
+        a.extra.resize(s.n_extra_prior_layers);
+        for (int z = 0; z < s.n_extra_prior_layers; ++z) {
+            rc = load_decoder_layer(c, own, s.extra_prior_layers[z], d, a.extra[z].dl, a.extra[z].w16);
+            if (rc) return rc;
+        }
         a.present = true;
     }
     HG_HIP(hipDeviceSynchronize());
@@ -663,9 +672,20 @@ int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const Ada
         for (int j = 0; j < 12; ++j) ad.dl[k][j] = a.dl[k][j];
         for (int j = 0; j < 6; ++j) ad.w16[k][j] = a.w16[k][j];
     }
-    // post-norm decoder layer over the 64-wide bottleneck (adapter...:186-200)
-    HG_HIP(launch_adapter_decoder((const float*)c->ad32.p, ad, ac.priors, ac.mask, n_seq, L, ac.priors ? ac.N : 0,
-                                  (float*)c->adkv.p, (half_t*)c->ad16.p, s));
+    // post-norm decoder layer(s) over the 64-wide bottleneck (adapter...:186-200); with adapter_num_layers > 1 the
+    // prior path chains mhsa_layers.0 .. N-1, the intermediate activations staying fp32 in place
+    const int n_chain = ac.priors ? 1 + (int)a.extra.size() : 1;
+    for (int z = 0; z < n_chain; ++z) {
+        if (z > 0)
+            for (int j = 0; j < 12; ++j) ad.dl[0][j] = a.extra[z - 1].dl[j];
+        if (z > 0)
+            for (int j = 0; j < 6; ++j) ad.w16[0][j] = a.extra[z - 1].w16[j];
+        hipError_t e = launch_adapter_decoder((const float*)c->ad32.p, ad, ac.priors, ac.mask, n_seq, L, ac.priors ? ac.N : 0,
+                                              (float*)c->adkv.p, (half_t*)c->ad16.p, s,
+                                              z + 1 < n_chain ? (float*)c->ad32.p : nullptr);
+        if (e != hipSuccess)
+            return fail(c, HG_ERR_HIP, "adapter decoder layer %d failed: %s", z, hipGetErrorString(e));
+    }
     // x += up_proj(.) * scale   (adapter...:201-202, :456)
     g = GemmArgs{};
     g.A = (const half_t*)c->ad16.p; g.lda = 64; g.W = a.up_w; g.bias = a.up_b; g.pos = a.scale; g.out = x; g.ldc = D;

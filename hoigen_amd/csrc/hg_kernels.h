@@ -168,8 +168,10 @@ struct AdapterDev {      // device pointers, all fp32 except the two MFMA operan
 };
 // down32 [M,128] fp32 (cols 0..63 = relu(down_proj(x))) -> out16 [M,64] fp16 (decoder layer output);
 // kv: scratch [B*Nmem, 2, 64] fp32 with Nmem = N (prior given) or L (prior == nullptr).
+// chain32 (optional, adapter_num_layers > 1): write the layer's output as fp32 into this [M,128] buffer (may be down32
+// itself) instead of out16, for the next decoder layer of the chain
 hipError_t launch_adapter_decoder(const float* down32, const AdapterDev& ad, const float* priors,
                                   const uint8_t* mask, int B, int L, int N, float* kv, half_t* out16,
-                                  hipStream_t s);
+                                  hipStream_t s, float* chain32 = nullptr);
 
 }  // namespace hg

@@ -159,7 +159,7 @@ def stress_clip_state_dict(cfg: dict = VIT_B16, seed: int = 0) -> "OrderedDict[s
 # ---------------------------------------------------------------------------------------------
 
 def adapter_state_dict(cfg: dict = VIT_B16, seed: int = 1, layers=None, bottleneck: int = 64,
-                       trained: bool = True) -> "OrderedDict[str, np.ndarray]":
+                       trained: bool = True, num_layers: int = 1) -> "OrderedDict[str, np.ndarray]":
     """Keys under ``visual.transformer.resblocks.{i}.adaptermlp.*``.
 
     ``trained=True`` gives non-zero ``up_proj`` and a visible ``scale`` so the adapter branch
@@ -186,7 +186,7 @@ def adapter_state_dict(cfg: dict = VIT_B16, seed: int = 1, layers=None, bottlene
             sd[pre + "up_proj.bias"] = np.zeros((vw,), np.float32)
         put("down_proj.weight", (d, vw), vw ** -0.5)
         put("down_proj.bias", (d,), 0.02)
-        for tw in ("mhsa_layers.0.", "mhsa."):
+        for tw in [f"mhsa_layers.{z}." for z in range(num_layers)] + ["mhsa."]:
             put(tw + "multihead_attn.in_proj_weight", (3 * d, d), d ** -0.5)
             put(tw + "multihead_attn.in_proj_bias", (3 * d,), 0.02)
             put(tw + "multihead_attn.out_proj.weight", (d, d), d ** -0.5)

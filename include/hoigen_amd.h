@@ -82,6 +82,10 @@ typedef struct {
     hg_tensor up_proj_weight, up_proj_bias;     /* [D, d], [D] */
     hg_decoder_layer_weights prior_layer;       /* mhsa_layers.0 (memory = prior tokens) */
     hg_decoder_layer_weights self_layer;        /* mhsa          (memory = down itself)  */
+    /* adapter_num_layers > 1 (CLIP_models_adapter_prior2.py:150,179,190-195): mhsa_layers.1 .. N-1, applied one after
+     * the other on the prior path; NULL / 0 for the default single layer */
+    int32_t n_extra_prior_layers;
+    const hg_decoder_layer_weights* extra_prior_layers;
 } hg_adapter_weights;
 
 /* VisionTransformer — clipnet/model.py:202-236 (variant A) and

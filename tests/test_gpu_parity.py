@@ -119,6 +119,28 @@ def test_tiny_variant_c_vs_reference(g1):
     check(g2_, g1["c_prior_global"], what="after adapter update")
 
 
+def test_tiny_variant_c_two_adapter_layers_vs_reference():
+    """adapter_num_layers = 2: the prior path chains mhsa_layers.0 and .1 (CLIP_models_adapter_prior2.py:179,190-195);
+    the no-prior path still uses the single `mhsa` layer.  Reference outputs: make_golden_adapter_layers.py."""
+    g = dict(np.load(f"{G}/g10_adapter_layers.npz"))
+    sd = synth.to_torch(synth.clip_state_dict(synth.TINY, 10))
+    sd.update(synth.to_torch(synth.adapter_state_dict(synth.TINY, 13, num_layers=2)))
+    m = build_model(sd, use_adapter=True, adapter_pos="all", adapter_num_layers=2).to(dev())
+    assert len(m.visual.transformer.resblocks[0].adaptermlp.mhsa_layers) == 2
+    img = torch.from_numpy(synth.crops(3, 32, seed=11)).to(dev())
+    pri, mask = synth.priors(3, n=6, dim=64, n_pad=2, seed=14)
+    gl, ll = m.visual(img, (torch.from_numpy(pri).to(dev()), torch.from_numpy(mask).to(dev())))
+    check(gl, g["prior_global"], what="C global, 2 adapter layers")
+    check(ll.permute(0, 2, 3, 1), np.transpose(g["prior_local"], (0, 2, 3, 1)), what="C local, 2 adapter layers")
+    gl, ll = m.visual(img, None)
+    check(gl, g["noprior_global"], what="C global, 2 adapter layers, no prior")
+    # one layer of the same weights gives a different answer (the second layer is really applied)
+    sd1 = {k: v for k, v in sd.items() if "mhsa_layers.1." not in k}
+    m1 = build_model(sd1, use_adapter=True, adapter_pos="all").to(dev())
+    g1_, _ = m1.visual(img, (torch.from_numpy(pri).to(dev()), torch.from_numpy(mask).to(dev())))
+    assert rel_l2(g1_, g["prior_global"])[0] > 1e-3
+
+
 def test_tiny_vae_chain_vs_reference(g1, tinyA):
     D = 128
     d = dev()
