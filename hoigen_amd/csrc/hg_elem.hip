@@ -542,6 +542,86 @@ __global__ __launch_bounds__(256) void rowstats_cast_kernel(const float* __restr
         if (muc) muc[r] = mean;
     }
 }
+// ln_pre and the first block's folding statistics in one pass (vision tower, LayerNorm folding on): y = LN(x) written in
+// place as fp32, then exactly rowstats_cast's arithmetic on the y values still in registers (same bits as the two kernels)
+__global__ __launch_bounds__(256) void layernorm_rowstats_kernel(float* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ b, half_t* __restrict__ x16,
+                                                                 float* __restrict__ mr, float* __restrict__ mu,
+                                                                 float* __restrict__ muc, int M, int D) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    f32x4* xp = reinterpret_cast<f32x4*>(x + (size_t)r * D);
+    const int nc = D >> 2;
+    f32x4 v[LN_MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nc) {
+            v[i] = xp[c];
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nc) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
+    const f32x4* wp = reinterpret_cast<const f32x4*>(w);
+    const f32x4* bp = reinterpret_cast<const f32x4*>(b);
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nc) {
+            const f32x4 g = wp[c], be = bp[c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] = (v[i][e] - mean) * rstd * g[e] + be[e];
+            xp[c] = v[i];
+            s2 += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mean2 = wave_sum(s2) / (float)D;
+    float q2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nc) {
+            half4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean2;
+                q2 += d * d;
+                h[e] = (half_t)d;
+            }
+            reinterpret_cast<half4*>(x16 + (size_t)r * D)[c] = h;
+        }
+    }
+    const float rstd2 = 1.0f / sqrtf(wave_sum(q2) / (float)D + 1e-5f);
+    if (lane == 0) {
+        mr[2 * (size_t)r] = 0.f;
+        mr[2 * (size_t)r + 1] = rstd2;
+        mu[r] = mean2;
+        if (muc) muc[r] = mean2;
+    }
+}
+hipError_t launch_layernorm_rowstats(float* x, const float* w, const float* b, half_t* x16, float* mr, float* mu, float* muc,
+                                     int M, int D, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    if (D % 4 || D > 256 * LN_MAXC) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_rowstats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, w, b, x16, mr, mu, muc, M, D);
+    return hipGetLastError();
+}
 hipError_t launch_rowstats_cast(const float* x, half_t* x16, float* mr, float* mu, int M, int D, hipStream_t s, float* muc) {
     if (M <= 0) return hipSuccess;
     if (D % 4 || D > 256 * LN_MAXC) return hipErrorInvalidValue;

@@ -131,6 +131,9 @@ hipError_t launch_fold_ln(const half_t* w16, const float* gamma, const float* be
 // x fp32 [M,D] -> centred fp16 copy x16 = fp16(x - mean), mu[m] = mean, mr[m] = (0, rstd) (eps 1e-5, biased variance)
 hipError_t launch_rowstats_cast(const float* x, half_t* x16, float* mr, float* mu, int M, int D, hipStream_t s,
                                 float* muc = nullptr);   // muc (optional): centre of the copy as well (= mu)
+// x = LayerNorm(x; w, b) in place (fp32) followed by rowstats_cast of the result, in one pass (ln_pre of the vision tower)
+hipError_t launch_layernorm_rowstats(float* x, const float* w, const float* b, half_t* x16, float* mr, float* mu, float* muc,
+                                     int M, int D, hipStream_t s);
 // stats [M][nt][2]: per column group of gw columns (sum, sum of squared deviations from the group mean)
 // -> mr [M][2] = (mean - mu[m], rstd) over the nt * gw columns, eps 1e-5, then mu[m] = mean (the centre the next
 // residual GEMM subtracts from its fp16 copy)
