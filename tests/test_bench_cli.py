@@ -32,3 +32,35 @@ def test_gpus_n_without_launcher_starts_child_ranks():
     assert r.returncode != 0
     assert r.stderr.count("bench.py needs a HIP device") >= 1
     assert "needs torch.distributed.run" not in r.stderr
+
+
+import json  # noqa: E402
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_line_schema_on_gpu():
+    """One short run of the real benchmark: the JSON line carries the contract's fields, the roofline of the dominant
+    kernel, the per-kernel table and the two extra configurations."""
+    r = _run(["--steps", "3", "--warmup", "1", "--no-cpu-baseline"], timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line"
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "kernels", "step_ms", "config3", "config4"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "crops/s" and d["dtype"] == "f16" and d["vs_baseline"] is None
+    assert abs(d["value"] - 256 * 1e3 / d["ms_per_step"]) < 1e-3 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and 0 < rf["frac"] < 1 and 0 < rf["e2e_frac"] < 1 and rf["launches_timed"] > 0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    # the dominant kernel is the one with the largest time share in the table, and the table accounts for the step
+    by_kernel = {}
+    for k in d["kernels"]:
+        by_kernel[k["kernel"]] = by_kernel.get(k["kernel"], 0.0) + k["ms_per_step"]
+    top = max(by_kernel, key=by_kernel.get)
+    assert rf["kernel"].startswith(top)
+    assert 0.8 * d["ms_per_step"] < sum(by_kernel.values()) < 1.05 * d["ms_per_step"]
+    assert d["config4"]["ms"] > 0 and d["config3"]["truncated"]["ms"] < d["config3"]["full_77_tokens"]["ms"]
