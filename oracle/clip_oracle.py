@@ -159,7 +159,10 @@ def adapter(x: Tensor, sd: Dict[str, Tensor], pre: str,
     down = torch.relu(linear(x, sd[pre + "down_proj.weight"], sd[pre + "down_proj.bias"]))
     if prior is not None:
         ctx, mask = prior
-        down = _decoder_layer_post(down, ctx.to(x.dtype), sd, pre + "mhsa_layers.0.", mask)
+        z = 0                              # adapter_num_layers clones, applied one after the other (:179,190-195)
+        while pre + f"mhsa_layers.{z}.linear1.weight" in sd:
+            down = _decoder_layer_post(down, ctx.to(x.dtype), sd, pre + f"mhsa_layers.{z}.", mask)
+            z += 1
     else:
         down = _decoder_layer_post(down, down, sd, pre + "mhsa.", None)
     up = linear(down, sd[pre + "up_proj.weight"], sd[pre + "up_proj.bias"])

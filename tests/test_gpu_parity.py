@@ -141,6 +141,30 @@ def test_tiny_variant_c_two_adapter_layers_vs_reference():
     assert rel_l2(g1_, g["prior_global"])[0] > 1e-3
 
 
+@pytest.mark.parametrize("n_prior,n_pad", [(1, 0), (30, 0), (30, 29), (17, 5)])
+def test_variant_c_prior_counts_and_masks_vs_oracle(n_prior, n_pad):
+    """The MFMA adapter decoder over the range of prior-token counts the detector produces (6 <= N <= 30,
+    upt...distill3.py:1378-1398; also the degenerate N = 1) and masks that leave a single valid key, against the oracle
+    on the tiny configuration; and at ViT-B/16 width on 5 crops (LayerNorm folding kept on behind the adapters)."""
+    from oracle import clip_oracle as co
+    for cfg, res, B, seed in ((synth.TINY, 32, 3, 31), (synth.VIT_B16, 224, 5, 32)):
+        if cfg is synth.VIT_B16 and (n_prior, n_pad) != (30, 29):
+            continue                                    # one full-width case is enough (CPU oracle time)
+        raw = synth.clip_state_dict(cfg, 10)
+        raw.update(synth.adapter_state_dict(cfg, 13))
+        m = build_model(synth.to_torch(raw), use_adapter=True, adapter_pos="all").to(dev())
+        img = torch.from_numpy(synth.crops(B, res, seed=seed))
+        pri = torch.from_numpy(synth.hg_normal((B, n_prior, 64), 700 + n_prior))
+        mask = torch.zeros(B, n_prior, dtype=torch.bool)
+        if n_pad:
+            mask[:, n_prior - n_pad:] = True
+        sd = co.as_tensors(raw)
+        want_g, want_l = co.visual_with_prior(sd, img, (pri, mask), adapter_layers=range(cfg["vision_layers"]))
+        got_g, got_l = m.visual(img.to(dev()), (pri.to(dev()), mask.to(dev())))
+        check(got_g, want_g.numpy(), what=f"global N={n_prior} pad={n_pad} width={cfg['vision_width']}")
+        check(got_l.permute(0, 2, 3, 1), want_l.permute(0, 2, 3, 1).numpy(), what=f"local N={n_prior} pad={n_pad}")
+
+
 def test_tiny_vae_chain_vs_reference(g1, tinyA):
     D = 128
     d = dev()

@@ -212,3 +212,18 @@ def test_g8_stress_outlier_channels():
     for i, r in enumerate(rows):
         ids[i, :len(r)] = r
     close(co.encode_text(sd, torch.from_numpy(ids)), g["encode_text"][:8], rel=1e-4)
+
+
+def test_g10_two_adapter_layers():
+    """adapter_num_layers = 2 (reference fixture make_golden_adapter_layers.py): the prior path chains both layers."""
+    g = dict(np.load(f"{G}/g10_adapter_layers.npz"))
+    raw = synth.clip_state_dict(synth.TINY, 10)
+    raw.update(synth.adapter_state_dict(synth.TINY, 13, num_layers=2))
+    sd = co.as_tensors(raw)
+    img = torch.from_numpy(synth.crops(3, 32, seed=11))
+    pri, mask = synth.priors(3, n=6, dim=64, n_pad=2, seed=14)
+    gl, ll = co.visual_with_prior(sd, img, (torch.from_numpy(pri), torch.from_numpy(mask)), adapter_layers=range(2))
+    close(gl, g["prior_global"], rel=1e-4)
+    close(ll, g["prior_local"], rel=1e-4)
+    gl, _ = co.visual_with_prior(sd, img, None, adapter_layers=range(2))
+    close(gl, g["noprior_global"], rel=1e-4)
