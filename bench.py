@@ -60,6 +60,8 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=BATCH, help="crops per GPU per step (metric is quoted at 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the config3 / config4 objects")
+    ap.add_argument("--no-class-rows", action="store_true",
+                    help="skip the second timed region (the library's default last block); for kernel traces of the headline alone")
     return ap.parse_args()
 
 
@@ -78,6 +80,8 @@ def self_launch(args) -> int:
         cmd.append("--no-cpu-baseline")
     if args.no_extra_configs:
         cmd.append("--no-extra-configs")
+    if args.no_class_rows:
+        cmd.append("--no-class-rows")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -354,12 +358,15 @@ def run(args):
     out = out.clone()                                    # (the gather buffers are reused by the next steps)
 
     # the library's default path (last block on the class-token rows only), same protocol
-    os.environ["HG_LAST_BLOCK_ROW0"] = "1"
-    for _ in range(args.warmup):
-        step()
-    dt2, per_step2, _, out2 = timed_region()
-    assert torch.isfinite(out2).all()
-    rel = float(((out2.float() - out.float()).norm() / out.float().norm()).item())
+    if args.no_class_rows:
+        dt2, rel = dt, 0.0
+    else:
+        os.environ["HG_LAST_BLOCK_ROW0"] = "1"
+        for _ in range(args.warmup):
+            step()
+        dt2, per_step2, _, out2 = timed_region()
+        assert torch.isfinite(out2).all()
+        rel = float(((out2.float() - out.float()).norm() / out.float().norm()).item())
 
     t = torch.tensor([dt, dt2], device=dev, dtype=torch.float64)
     if world > 1:
@@ -413,13 +420,14 @@ def run(args):
         }
         v2 = world * args.batch * args.steps / dt2
         f2 = FLOPS_PER_CROP - FLOPS_DEAD_ROWS
-        line["class_rows_only"] = {
-            "what": "library default: last block = K/V for all rows, then attention / out-proj / MLP for the class-token "
-                    "row only (rows that cannot reach the embedding are not computed)",
-            "value": round(v2, 2), "unit": "crops/s", "ms_per_step": round(dt2 / args.steps * 1e3, 4),
-            "flops_per_crop_executed": round(f2 / 1e9, 3),
-            "e2e_frac": round(v2 / world * f2 / 1e12 / MFMA_PEAK_TFLOPS, 4),
-            "rel_l2_vs_all_rows": float(f"{rel:.3e}")}
+        if not args.no_class_rows:
+            line["class_rows_only"] = {
+                "what": "library default: last block = K/V for all rows, then attention / out-proj / MLP for the class-token "
+                        "row only (rows that cannot reach the embedding are not computed)",
+                "value": round(v2, 2), "unit": "crops/s", "ms_per_step": round(dt2 / args.steps * 1e3, 4),
+                "flops_per_crop_executed": round(f2 / 1e9, 3),
+                "e2e_frac": round(v2 / world * f2 / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                "rel_l2_vs_all_rows": float(f"{rel:.3e}")}
         if world == 1:
             with_cpu = not args.no_cpu_baseline
             if with_cpu:
