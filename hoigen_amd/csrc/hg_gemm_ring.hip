@@ -66,7 +66,7 @@ template <int MF, int EPI, bool PH2>
 __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int tiles_n, const int n_tiles,
                                                     const unsigned a_bytes, const int mode, const int gsz) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins (buffer resources, LDS DMA): host sees just the stub
-    // timing-experiment switches (HG_RING_MODE bits 1 locality, 2 no MFMA, 4 no epilogue, 8 no stagger, 16 coalesced
+    // timing-experiment switches (HG_RING_MODE bits 1 locality, 2 no MFMA, 4 no epilogue, 8 no stagger, 32 no fragment reads, 64 no operand DMA, 16 coalesced
     // stores) exist only in a -DHG_EXPERIMENTS build: run-time branches in the K loop cost several per cent
 #ifdef HG_EXPERIMENTS
     const int xmode = mode;
@@ -198,11 +198,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     using P1 = std::integral_constant<int, 1>;
     auto dma_A = [&](int h, auto I) {
         constexpr int i = decltype(I)::value;
+        if (xmode & 64) return;   // timing experiment: no operand DMA
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (HG_LDS void*)(smem + ld_buf + h * AH + wave * GA * 1024), 16,
                                                  voffA[h][i], ld_sA + ld_kt * (BK * 2), i * 1024, 0);
     };
     auto dma_W = [&](int h, auto I) {
         constexpr int i = decltype(I)::value;
+        if (xmode & 64) return;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (HG_LDS void*)(smem + ld_buf + 2 * AH + h * BH + wave * GB * 1024),
                                                  16, voffW[h][i], ld_sW + ld_kt * (BK * 2), i * 1024, 0);
     };
@@ -227,7 +229,21 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
 
     // Fragment registers: one A set (half 0 in P1-P2, half 1 in P3-P4) and both W halves.
     half8 xa[MF][2], wb[2][2][2];
+#ifdef HG_EXPERIMENTS
+    if (xmode & 32) {   // defined (opaque) fragment values for the no-read experiment
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int f = 0; f < MF; ++f) asm volatile("v_mov_b32 %0, 0\n v_mov_b32 %1, 0\n v_mov_b32 %2, 0\n v_mov_b32 %3, 0" : "=v"(((int*)&xa[f][ks])[0]), "=v"(((int*)&xa[f][ks])[1]), "=v"(((int*)&xa[f][ks])[2]), "=v"(((int*)&xa[f][ks])[3]));
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) asm volatile("v_mov_b32 %0, 0\n v_mov_b32 %1, 0\n v_mov_b32 %2, 0\n v_mov_b32 %3, 0" : "=v"(((int*)&wb[h][g2][ks])[0]), "=v"(((int*)&wb[h][g2][ks])[1]), "=v"(((int*)&wb[h][g2][ks])[2]), "=v"(((int*)&wb[h][g2][ks])[3]));
+        }
+    }
+#endif
     auto read_A = [&](int h, int buf) {
+        if (xmode & 32) return;   // timing experiment: no fragment reads
 #pragma unroll
         for (int f = 0; f < MF; ++f)
 #pragma unroll
@@ -236,6 +252,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     };
     auto read_W = [&](auto H, int buf) {
         constexpr int h = decltype(H)::value;
+        if (xmode & 32) return;
 #pragma unroll
         for (int g2 = 0; g2 < 2; ++g2)
 #pragma unroll
