@@ -870,7 +870,7 @@ int hg_test_attention(hg_ctx* c, const float* qkv, const float* q0, const int32_
                                      heads, causal != 0, s));
         HG_HIP(launch_f16_to_f32((const half_t*)c->att.p, out, (size_t)n_seq * D, s));
     } else {
-        HG_HIP(launch_attention((const half_t*)c->qkv.p, (half_t*)c->att.p, n_seq, L, heads, causal != 0, s));
+        HG_HIP(attention(c, (const half_t*)c->qkv.p, (half_t*)c->att.p, n_seq, L, heads, causal != 0, s));
         HG_HIP(launch_f16_to_f32((const half_t*)c->att.p, out, M * D, s));
     }
     return HG_OK;

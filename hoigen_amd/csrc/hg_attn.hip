@@ -15,6 +15,8 @@
 // The running max only triggers a rescale of O when some query's max actually grew (wave-uniform
 // branch).  Softmax statistics and accumulation are fp32; masking (keys >= L, causal diagonal) is
 // applied only on the tiles that need it.
+#include <stdlib.h>
+
 #include "hg_kernels.h"
 
 namespace hg {
@@ -34,7 +36,14 @@ __device__ __forceinline__ int swz_v(int row) { return ((row >> 1) & 1) << 2; } 
 template <bool CAUSAL, bool ROW0>
 __global__ __launch_bounds__(448) void attention_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
                                                         int L, int heads, int nkt, const half_t* __restrict__ q0,
-                                                        const int32_t* __restrict__ sel) {
+                                                        const int32_t* __restrict__ sel, const int mode) {
+    // timing-experiment switches (HG_ATTN_MODE bits 1 no key loop, 2 no K/V staging, 4 no stores, 8 no Q loads; wrong results) exist
+    // only in a -DHG_EXPERIMENTS build
+#ifdef HG_EXPERIMENTS
+    const int xmode = mode;
+#else
+    constexpr int xmode = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // K and V rows 0 .. rs-1 are staged, rs = L rounded up to 16 (the last key tile may be half present: its second
     // 16-key step is skipped in P V, its missing K rows read into the V region and are masked)
@@ -50,7 +59,7 @@ __global__ __launch_bounds__(448) void attention_kernel(const half_t* __restrict
     const half_t* base = qkv + (size_t)seq * L * ld + head * HD;
 
     // ---- stage K and V: piece = 8 rows x 128 B; lane -> (row = l>>3, chunk' = l&7)
-    for (int piece = wave; piece < rs / 8; piece += nwaves) {
+    for (int piece = wave; piece < ((xmode & 2) ? 0 : rs / 8); piece += nwaves) {
         const int row = piece * 8 + (lane >> 3);
         const int src_row = row < L ? row : L - 1;
         const half_t* rp = base + (size_t)src_row * ld;
@@ -69,7 +78,10 @@ __global__ __launch_bounds__(448) void attention_kernel(const half_t* __restrict
     const half_t* qp = ROW0 ? q0 + (size_t)seq * D + head * HD + hh * 8 : base + (size_t)(q < L ? q : L - 1) * ld + hh * 8;
     half8 qf[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const half8*>(qp + ks * 16);
+    for (int ks = 0; ks < 4; ++ks) {
+        if (xmode & 8) qf[ks] = half8{0, 0, 0, 0, 0, 0, 0, 0};   // timing experiment: no Q loads
+        else qf[ks] = *reinterpret_cast<const half8*>(qp + ks * 16);
+    }
 
     __syncthreads();   // K/V landed (the barrier's fence waits for the LDS-DMA: vmcnt(0))
     if constexpr (ROW0) {
@@ -100,7 +112,7 @@ __global__ __launch_bounds__(448) void attention_kernel(const half_t* __restrict
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
 
-    const int kt_end = CAUSAL ? (qt + 1 < nkt ? qt + 1 : nkt) : nkt;
+    const int kt_end = (xmode & 1) ? 0 : (CAUSAL ? (qt + 1 < nkt ? qt + 1 : nkt) : nkt);
     for (int kt = 0; kt < kt_end; ++kt) {
         // ---- S^T tile: lane holds keys kt*32 + (r&3) + 8*(r>>2) + 4*hh of query q
         f32x16 s;
@@ -172,8 +184,25 @@ __global__ __launch_bounds__(448) void attention_kernel(const half_t* __restrict
     lsum += __shfl_xor(lsum, 32, 64);
     const float inv = 1.0f / lsum;
     // ---- store: lane = query q, d = dt*32 + (r&3) + 8*(r>>2) + 4*hh
-    if (ROW0 ? qcol == 0 : q < L) {
-        half_t* op = out + (ROW0 ? (size_t)seq : (size_t)seq * L + q) * D + head * HD;
+    if constexpr (ROW0) {
+        if (qcol == 0 && !(xmode & 4)) {
+            half_t* op = out + (size_t)seq * D + head * HD;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    half4 h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[e] = (half_t)(o[dt][g * 4 + e] * inv);
+                    *reinterpret_cast<half4*>(op + dt * 32 + 8 * g + 4 * hh) = h;
+                }
+        }
+    } else {
+        // Row-per-lane 8-byte stores touch 32 cache lines per instruction (29 us of a 100 us kernel); instead the
+        // wave's 32 x 64 tile goes through LDS (the K/V rows are dead once every wave has left the key loop; 16-byte
+        // chunks XOR-swizzled by row) and leaves as whole 128-byte rows: lane -> (row = l >> 3, chunk = l & 7).
+        __syncthreads();
+        char* ot = smem + wave * 4096;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -181,8 +210,16 @@ __global__ __launch_bounds__(448) void attention_kernel(const half_t* __restrict
                 half4 h;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) h[e] = (half_t)(o[dt][g * 4 + e] * inv);
-                *reinterpret_cast<half4*>(op + dt * 32 + 8 * g + 4 * hh) = h;
+                *reinterpret_cast<half4*>(ot + qcol * 128 + (((dt * 4 + g) ^ (qcol & 7)) << 4) + hh * 8) = h;
             }
+        const int cr = lane >> 3, cc = lane & 7;
+#pragma unroll
+        for (int rb = 0; rb < 32; rb += 8) {
+            const int row = rb + cr, qq = qt * 32 + row;
+            const half8 v = *reinterpret_cast<const half8*>(ot + row * 128 + ((cc ^ (row & 7)) << 4));
+            if (qq < L && !(xmode & 4))
+                *reinterpret_cast<half8*>(out + ((size_t)seq * L + qq) * D + head * HD + cc * 8) = v;
+        }
     }
 }
 
@@ -199,7 +236,9 @@ static hipError_t launch_t(const half_t* qkv, half_t* out, int n_seq, int L, int
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((attention_kernel<CAUSAL, ROW0>), dim3(n_seq * heads), dim3(64 * nkt), lds, s, qkv, out, L, heads, nkt, q0, sel);
+    static const int mode = getenv("HG_ATTN_MODE") ? atoi(getenv("HG_ATTN_MODE")) : 0;   // read by experiment builds only
+    hipLaunchKernelGGL((attention_kernel<CAUSAL, ROW0>), dim3(n_seq * heads), dim3(64 * nkt), lds, s, qkv, out, L, heads, nkt, q0, sel,
+                       mode);
     return hipGetLastError();
 }
 
