@@ -29,9 +29,10 @@ __device__ __forceinline__ int swz_k(int row) { return (row >> 1) & 7; }        
 __device__ __forceinline__ int swz_v(int row) { return ((row >> 1) & 1) << 2; }   // tr_b16 reads
 
 // One 32-key tile of the online softmax for this wave's 32 queries (lane = query qcol, key half hh), in two parts so
-// that the streaming kernel can reload its Q registers in between: tile_scores() S^T = K_tile Q^T; tile_softmax_pv()
+// that a caller can reuse its Q registers in between: tile_scores() S^T = K_tile Q^T; tile_softmax_pv()
 // running max / rescale, P, O^T += V_tile^T P^T.  kb / vb: LDS bases of the tile's K and V rows.  Shared by the
-// whole-sequence kernel, its one-row variant and the streaming kernel, so the three are bit-identical.
+// whole-sequence kernel and its one-row variant, so the two are bit-identical (a streaming kernel over an LDS ring of
+// key tiles and a persistent variant were built on the same two functions and measured slower: DESIGN.md section 4).
 __device__ __forceinline__ void tile_scores(const char* kb, const int (&k_off)[4], const half8 (&qf)[4], f32x16& s) {
     // ---- S^T tile: lane holds keys kt*32 + (r&3) + 8*(r>>2) + 4*hh of query q
 #pragma unroll
@@ -86,7 +87,7 @@ __device__ __forceinline__ void tile_softmax_pv(const char* vb, const int (&v_of
     lsum += ps;
     // ---- O^T[d][q] += sum_key V[key][d] P[q][key]; element j of lane half hh is key 16s + 8(j>>2) + 4hh + (j&3)
     // The transposing reads are inline asm: the compiler's waitcnt pass gives the builtin no memory operand and puts
-    // vmcnt(0) in front of it while LDS-DMA is in flight (the streaming kernel); lgkmcnt is therefore waited here.
+    // vmcnt(0) in front of it whenever LDS-DMA is in flight; lgkmcnt is therefore waited here.
 #pragma unroll
     for (int sstep = 0; sstep < 2; ++sstep) {
         if (sstep == 1 && kt * 32 + 16 >= rs) break;      // keys beyond the staged rows (all masked): wave-uniform
@@ -245,300 +246,6 @@ __global__ __launch_bounds__(448) void attention_kernel(const half_t* __restrict
     }
 }
 
-// ---- streaming variant (non-causal, 5 <= nkt <= 7 key tiles: the ViT shapes) -------------------------------------
-// The whole-sequence kernel's workgroups are load -> compute -> store phases with nothing in flight between them
-// (two workgroups per CU: 94 VGPRs); measured by knock-outs, its memory phases (58 us) and its key loop (58 us) overlap
-// to 84 us.  Here a persistent workgroup (one wave per 32-query tile, as above) walks a list of (sequence, head)
-// items and treats their key tiles as ONE stream through an LDS ring of S stages (K tile 4 KiB | V tile 4 KiB): tile
-// g + S - 1 is requested while tile g is computed, across item boundaries, so the loads of the next item run under
-// the key loop of this one; the next item's Q fragments are prefetched into registers and the output tile leaves
-// through a wave-private 4 KiB LDS slot as whole rows.  One workgroup barrier per key tile; the DMA waits are counted
-// (vmcnt), with the Q loads and output stores that sit between a tile's request and its use accounted for.
-static constexpr int SR = 6;                       // ring stages
-static constexpr int STAGEB = 2 * TILEB;           // K tile | V tile
-
-template <int N>
-__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void wait_vm_rt(int n) {   // s_waitcnt vmcnt(n) for a wave-uniform run-time n (clamped to 16)
-    switch (n) {
-#define HG_VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-        HG_VMC(0) HG_VMC(1) HG_VMC(2) HG_VMC(3) HG_VMC(4) HG_VMC(5) HG_VMC(6) HG_VMC(7) HG_VMC(8) HG_VMC(9) HG_VMC(10)
-        HG_VMC(11) HG_VMC(12) HG_VMC(13) HG_VMC(14) HG_VMC(15)
-#undef HG_VMC
-        default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-    }
-}
-
-__global__ __launch_bounds__(448, 4) void attention_stream_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
-                                                               const int L, const int heads, const int nkt,
-                                                               const int n_items, const int mode) {
-#ifdef HG_EXPERIMENTS
-    const int xmode = mode;
-#else
-    constexpr int xmode = 0;
-#endif
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int D = heads * HD;
-    const size_t ld = (size_t)3 * D;
-    const int G = gridDim.x;
-    const int my_items = (n_items - (int)blockIdx.x + G - 1) / G;     // items blockIdx.x, + G, ...
-    if (my_items <= 0) return;
-    const int n_tiles = my_items * nkt;                               // this workgroup's key-tile stream
-    char* ot = smem + SR * STAGEB + wave * 4096;                      // output staging, private to the wave
-    const int rs = (L + 15) & ~15;
-
-    // ---- DMA: a tile is 8 pieces of 8 rows x 128 B (0-3 K, 4-7 V); wave w requests pieces w, w + nkt (< 8).
-    // buffer_load ... lds over a per-sequence resource (the global_load_lds form makes the compiler's waitcnt pass
-    // put vmcnt(0) in front of every LDS read).  A wave issues ~5 instructions per cycle-quad at best, so the per-tile
-    // skeleton is kept to a few dozen instructions: the load cursor (item -> sequence / head, key tile, stage) is
-    // incremental, the resource is rebuilt once per item, lane-constant address parts sit in four VGPRs.
-    const int pieces = 1 + (wave + nkt < 8 ? 1 : 0);
-    const int gq = G / heads, gr = G - gq * heads;                    // item += G  ->  (seq += gq, head += gr) with carry
-    int ld_seq = (int)blockIdx.x / heads, ld_head = (int)blockIdx.x - ld_seq * heads;
-    int ld_kt = 0, ld_stage = 0, ld_left = n_tiles;
-    const int ld2 = (int)(ld * 2);
-    const unsigned seq_bytes = (unsigned)((size_t)L * ld * 2);
-    __amdgpu_buffer_rsrc_t rs_seq =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(qkv + (size_t)ld_seq * L * ld), 0, seq_bytes, 0x00020000);
-    int ld_col = (ld_head * HD + D) * 2;                               // byte column of this head's K (V: + 2 D)
-    // piece j of this wave: rows pc_row[j] + lane>>3 of the tile, swizzled 16-byte chunk, K or V
-    int p_row[2], p_cb[2], p_lds[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int pc = wave + j * nkt, rl = (pc & 3) * 8 + (lane >> 3);
-        p_row[j] = rl;
-        p_cb[j] = (pc < 4 ? ((lane & 7) ^ swz_k(rl)) << 4 : 2 * D + (((lane & 7) ^ swz_v(rl)) << 4));
-        p_lds[j] = (pc < 4 ? 0 : TILEB) + (pc & 3) * 1024;
-    }
-    auto issue_next = [&]() {
-        if (ld_left <= 0) return;
-        char* st = smem + ld_stage * STAGEB;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if ((j == 0 || pieces == 2) && !(xmode & 2)) {
-                const int row = ld_kt * 32 + p_row[j];
-                const int r = row < L ? row : L - 1;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_seq, (HG_LDS void*)(st + p_lds[j]), 16, r * ld2 + p_cb[j], ld_col, 0, 0);
-            }
-        }
-        --ld_left;
-        ld_stage = ld_stage + 1 == SR ? 0 : ld_stage + 1;
-        if (++ld_kt == nkt) {
-            ld_kt = 0;
-            ld_seq += gq;
-            ld_head += gr;
-            if (ld_head >= heads) { ld_head -= heads; ++ld_seq; }
-            rs_seq = __builtin_amdgcn_make_buffer_rsrc((void*)(qkv + (size_t)ld_seq * L * ld), 0, seq_bytes, 0x00020000);
-            ld_col = (ld_head * HD + D) * 2;
-        }
-    };
-    const int qcol = lane & 31, hh = lane >> 5;
-    // Q fragments (B operand: lane = query, 8 consecutive d per k-step) straight from global.  Inline asm, so that the
-    // compiler's own waitcnt pass does not drain the DMA ring for them: the loads of item it + 1 are issued inside the
-    // last key tile of item it, right after its S^T MFMAs (the registers are dead from there), and only the item's output
-    // stores are younger: the first wait of item it + 1 allows for exactly those; pin_q() ties the registers to it.
-    auto load_q = [&](int seq, int head, half8 (&qd)[4]) {
-        const int q = wave * 32 + qcol;
-        const half_t* qp = qkv + (size_t)seq * L * ld + head * HD + (size_t)(q < L ? q : L - 1) * ld + hh * 8;
-        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:32\n\t"
-                     "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %4, off offset:96"
-                     : "=&v"(qd[0]), "=&v"(qd[1]), "=&v"(qd[2]), "=&v"(qd[3])
-                     : "v"(qp)
-                     : "memory");
-    };
-    auto pin_q = [&](half8 (&qd)[4]) { asm volatile("" : "+v"(qd[0]), "+v"(qd[1]), "+v"(qd[2]), "+v"(qd[3])::"memory"); };
-    // output stores per item that have at least one active lane (rows wave*32 + rb < L); a store the compiler issues
-    // with no active lane only makes the counted waits stricter
-    const int rows_left = L - wave * 32;
-    const int nst = rows_left <= 0 ? 0 : (rows_left >= 32 ? 4 : (rows_left + 7) >> 3);
-
-    // lane-constant LDS offsets (as in attention_kernel)
-    int k_off[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) k_off[ks] = qcol * ROWB + (((2 * ks + hh) ^ swz_k(qcol)) << 4);
-    const int gi = lane >> 4, l16 = lane & 15;
-    const int vq = l16 >> 2, vp = l16 & 3;
-    int v_off[2];
-    {
-        const int key0 = 4 * (gi >> 1) + vq;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            const int chunk = dt * 4 + (gi & 1) * 2 + (vp >> 1);
-            v_off[dt] = key0 * ROWB + ((chunk ^ swz_v(key0)) << 4) + (vp & 1) * 8;
-        }
-    }
-    const float c = 0.125f * 1.4426950408889634f;
-
-    // ---- prologue: Q of item 0, then tiles 0 .. SR-2
-    half8 qf[4];
-    int c_seq = ld_seq, c_head = ld_head;         // the item being computed; (n_seq, n_head): the one after it
-    load_q(c_seq, c_head, qf);
-    for (int g = 0; g < SR - 1; ++g) issue_next();
-
-    int stage = 0;
-    // per-wave wait immediates (see the loop): steady state, steps 1 .. SR-2 of an item, step 0 of an item
-    const int n_steady = (SR - 2) * pieces, n_after = n_steady + 4 + nst;
-    for (int it = 0; it < my_items; ++it) {
-        const bool last = it + 1 == my_items;
-        int n_seq_ = c_seq + gq, n_head = c_head + gr;
-        if (n_head >= heads) { n_head -= heads; ++n_seq_; }
-        float m = -1.0e30f, lsum = 0.f;
-        f32x16 o[2];
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-        for (int kt = 0; kt < nkt; ++kt) {
-            // memory operations of this wave younger than tile g's pieces: the pieces of tiles g+1 .. g+SR-2, plus the
-            // previous item's last step (Q loads of this item, then its output stores) if it lies in steps g-SR+1 ..
-            // g-1, i.e. kt <= SR-2.  At kt = 0 the Q loads themselves are needed: only the stores are younger.  The last
-            // item waits for everything (no younger pieces are issued any more).
-            if (last) wait_vm<0>();
-            else if (it > 0 && kt == 0) wait_vm_rt(nst);
-            else if (it > 0 && kt <= SR - 2) wait_vm_rt(n_after);
-            else if (pieces == 2) wait_vm<2 * (SR - 2)>();
-            else wait_vm<SR - 2>();
-            if (kt == 0) pin_q(qf);               // this item's Q fragments have landed
-            asm volatile("s_barrier" ::: "memory");   // tile g visible to every wave; every wave is past tile g-1
-            issue_next();                         // tile g + SR - 1, into the stage tile g - 1 has left
-            const char* st = smem + stage * STAGEB;
-            if (!(xmode & 1)) {
-                f32x16 sc;
-                tile_scores(st, k_off, qf, sc);
-                if (kt + 1 == nkt && !last) load_q(n_seq_, n_head, qf);      // the Q registers are dead from here
-                tile_softmax_pv<false>(st + TILEB, v_off, sc, kt, wave, wave * 32 + qcol, L, rs, hh, c, m, lsum, o);
-            }
-            stage = stage + 1 == SR ? 0 : stage + 1;
-        }
-        lsum += __shfl_xor(lsum, 32, 64);
-        const float inv = 1.0f / lsum;
-        const int seq = c_seq, head = c_head;
-        c_seq = n_seq_;
-        c_head = n_head;
-        int le = lane;                           // opaque copy: the staging addresses are not hoisted into the key loop
-        asm volatile("" : "+v"(le));
-        const int qce = le & 31, hhe = le >> 5;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                half4 h;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = (half_t)(o[dt][gq * 4 + e] * inv);
-                *reinterpret_cast<half4*>(ot + qce * 128 + (((dt * 4 + gq) ^ (qce & 7)) << 4) + hhe * 8) = h;
-            }
-        const int cr = le >> 3, cc = le & 7;
-#pragma unroll
-        for (int rb = 0; rb < 32; rb += 8) {
-            const int row = rb + cr, qq = wave * 32 + row;
-            const half8 v = *reinterpret_cast<const half8*>(ot + row * 128 + ((cc ^ (row & 7)) << 4));
-            if (qq < L && !(xmode & 4))
-                *reinterpret_cast<half8*>(out + ((size_t)seq * L + qq) * D + head * HD + cc * 8) = v;
-        }
-    }
-}
-
-// ---- persistent whole-sequence variant (non-causal): the kernel above with a loop over (sequence, head) items and a
-// start delay for every second workgroup.  Two workgroups share a CU (94 VGPRs), start together and take the same
-// time, so without the delay they stay in phase for the whole launch: both load, both compute, both store - the
-// knock-outs show memory phases (45 us) and key loops (45 us) adding up instead of overlapping.
-__global__ __launch_bounds__(448) void attention_persist_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
-                                                                const int L, const int heads, const int nkt,
-                                                                const int n_items, const int delay, const int mode) {
-#ifdef HG_EXPERIMENTS
-    const int xmode = mode;
-#else
-    constexpr int xmode = 0;
-#endif
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int rs = (L + 15) & ~15;
-    char* Ks = smem;
-    char* Vs = smem + rs * ROWB;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nwaves = blockDim.x >> 6;
-    const int D = heads * HD;
-    const size_t ld = (size_t)3 * D;
-    const int G = gridDim.x;
-    // the second half of the grid (the second workgroup of every CU under in-order dispatch) starts `delay` x 64 clocks late
-    if ((int)blockIdx.x >= (G >> 1))
-        for (int i = 0; i < delay; ++i) __builtin_amdgcn_s_sleep(1);
-
-    const int qt = wave, qcol = lane & 31, hh = lane >> 5;
-    int k_off[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) k_off[ks] = qcol * ROWB + (((2 * ks + hh) ^ swz_k(qcol)) << 4);
-    const int gi = lane >> 4, l16 = lane & 15;
-    const int vq = l16 >> 2, vp = l16 & 3;
-    int v_off[2];
-    {
-        const int key0 = 4 * (gi >> 1) + vq;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            const int chunk = dt * 4 + (gi & 1) * 2 + (vp >> 1);
-            v_off[dt] = key0 * ROWB + ((chunk ^ swz_v(key0)) << 4) + (vp & 1) * 8;
-        }
-    }
-    const float c = 0.125f * 1.4426950408889634f;
-    const int q = qt * 32 + qcol;
-
-    for (int item = blockIdx.x; item < n_items; item += G) {
-        const int seq = item / heads, head = item - seq * heads;
-        const half_t* base = qkv + (size_t)seq * L * ld + head * HD;
-        for (int piece = wave; piece < ((xmode & 2) ? 0 : rs / 8); piece += nwaves) {
-            const int row = piece * 8 + (lane >> 3);
-            const int src_row = row < L ? row : L - 1;
-            const half_t* rp = base + (size_t)src_row * ld;
-            const int cp = lane & 7;
-            glds16(rp + D + ((cp ^ swz_k(row)) << 3), Ks + piece * 1024);
-            glds16(rp + 2 * D + ((cp ^ swz_v(row)) << 3), Vs + piece * 1024);
-        }
-        const half_t* qp = base + (size_t)(q < L ? q : L - 1) * ld + hh * 8;
-        half8 qf[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (xmode & 8) qf[ks] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-            else qf[ks] = *reinterpret_cast<const half8*>(qp + ks * 16);
-        }
-        __syncthreads();   // K/V landed
-        float m = -1.0e30f, lsum = 0.f;
-        f32x16 o[2];
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-        for (int kt = 0; kt < ((xmode & 1) ? 0 : nkt); ++kt) {
-            f32x16 sc;
-            tile_scores(Ks + kt * TILEB, k_off, qf, sc);
-            tile_softmax_pv<false>(Vs + kt * TILEB, v_off, sc, kt, qt, q, L, rs, hh, c, m, lsum, o);
-        }
-        lsum += __shfl_xor(lsum, 32, 64);
-        const float inv = 1.0f / lsum;
-        __syncthreads();   // every wave has left the key loop: the K/V rows become the output staging area
-        char* ot = smem + wave * 4096;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                half4 h;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = (half_t)(o[dt][g * 4 + e] * inv);
-                *reinterpret_cast<half4*>(ot + qcol * 128 + (((dt * 4 + g) ^ (qcol & 7)) << 4) + hh * 8) = h;
-            }
-        const int cr = lane >> 3, cc = lane & 7;
-#pragma unroll
-        for (int rb = 0; rb < 32; rb += 8) {
-            const int row = rb + cr, qq = qt * 32 + row;
-            const half8 v = *reinterpret_cast<const half8*>(ot + row * 128 + ((cc ^ (row & 7)) << 4));
-            if (qq < L && !(xmode & 4))
-                *reinterpret_cast<half8*>(out + ((size_t)seq * L + qq) * D + head * HD + cc * 8) = v;
-        }
-        __syncthreads();   // staging reads done before the next item's K/V rows arrive
-    }
-}
-
 template <bool CAUSAL, bool ROW0 = false>
 static hipError_t launch_t(const half_t* qkv, half_t* out, int n_seq, int L, int heads, hipStream_t s,
                            const half_t* q0 = nullptr, const int32_t* sel = nullptr) {
@@ -558,54 +265,10 @@ static hipError_t launch_t(const half_t* qkv, half_t* out, int n_seq, int L, int
     return hipGetLastError();
 }
 
-static hipError_t launch_stream(const half_t* qkv, half_t* out, int n_seq, int L, int heads, hipStream_t s) {
-    const int nkt = (L + 31) / 32, n_items = n_seq * heads;
-    const int lds = SR * STAGEB + nkt * 4096;
-    static int cus_d[HG_MAX_DEVICES] = {};
-    int& cus = cus_d[current_device_index()];
-    if (!cus) {
-        int dev = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_stream_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, SR * STAGEB + 7 * 4096);
-        if (e != hipSuccess) { cus = 0; return e; }
-    }
-    static const int mode = getenv("HG_ATTN_MODE") ? atoi(getenv("HG_ATTN_MODE")) : 0;   // read by experiment builds only
-    static const int per_cu = getenv("HG_ATTN_WGS") ? atoi(getenv("HG_ATTN_WGS")) : 2;
-    const int grid = n_items < per_cu * cus ? n_items : per_cu * cus;
-    hipLaunchKernelGGL(attention_stream_kernel, dim3(grid), dim3(64 * nkt), lds, s, qkv, out, L, heads, nkt, n_items, mode);
-    return hipGetLastError();
-}
-
 hipError_t launch_attention(const half_t* qkv, half_t* out, int n_seq, int L, int heads, bool causal,
                             hipStream_t s) {
     if (n_seq <= 0) return hipSuccess;
     if (L < 1 || L > 224) return hipErrorInvalidValue;
-    // the streaming kernel's wait accounting needs at least SR - 1 key tiles per item (L >= 129: the ViT shapes)
-    static const int variant = getenv("HG_ATTN_VARIANT") ? atoi(getenv("HG_ATTN_VARIANT")) : 0;   // 1 stream, 2 persistent
-    if (!causal && variant == 1 && (L + 31) / 32 >= SR - 1) return launch_stream(qkv, out, n_seq, L, heads, s);
-    if (!causal && variant == 2) {
-        const int nkt = (L + 31) / 32, n_items = n_seq * heads;
-        static int cus_d[HG_MAX_DEVICES] = {};
-        int& cus = cus_d[current_device_index()];
-        if (!cus) {
-            int dev = 0;
-            hipError_t e = hipGetDevice(&dev);
-            if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_persist_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 7 * TILEB);
-            if (e != hipSuccess) { cus = 0; return e; }
-        }
-        static const int mode = getenv("HG_ATTN_MODE") ? atoi(getenv("HG_ATTN_MODE")) : 0;
-        static const int delay = getenv("HG_ATTN_DELAY") ? atoi(getenv("HG_ATTN_DELAY")) : 128;
-        const int grid = n_items < 2 * cus ? n_items : 2 * cus;
-        hipLaunchKernelGGL(attention_persist_kernel, dim3(grid), dim3(64 * nkt), 2 * ((L + 15) & ~15) * ROWB, s, qkv, out, L,
-                           heads, nkt, n_items, delay, mode);
-        return hipGetLastError();
-    }
     return causal ? launch_t<true>(qkv, out, n_seq, L, heads, s) : launch_t<false>(qkv, out, n_seq, L, heads, s);
 }
 
