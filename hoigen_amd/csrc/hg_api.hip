@@ -834,12 +834,22 @@ int hg_test_gemm(hg_ctx* c, const float* a, const float* w, const float* bias, f
     if (!rc) rc = ensure(c, c->att, (size_t)N * K * 2);
     const bool f16out = (epi == EPI_BIAS_F16 || epi == EPI_BIAS_QGELU_F16 || epi == EPI_BIAS_RELU_F16);
     if (!rc && f16out) rc = ensure(c, c->qkv, rup(M, 256) * N * 2);
+    // EPI_RESID_LN_F32 (timing only): centred fp16 copy into the qkv buffer, partial statistics + zero centres into cq
+    const bool rln = (epi == EPI_RESID_LN_F32);
+    const int sld = 4 * N / 256;
+    if (!rc && rln) rc = ensure(c, c->qkv, rup(M, 256) * N * 2);
+    if (!rc && rln) rc = ensure(c, c->cq, rup(M, 256) * (size_t)(2 * sld + 1) * 4);
     if (rc) return rc;
     HG_HIP(launch_f32_to_f16(a, (half_t*)c->h.p, (size_t)M * K, s));
     HG_HIP(launch_f32_to_f16(w, (half_t*)c->att.p, (size_t)N * K, s));
     GemmArgs g{};
     g.A = (half_t*)c->h.p; g.lda = K; g.W = (half_t*)c->att.p; g.bias = bias; g.M = M; g.N = N; g.K = K;
     g.out = f16out ? c->qkv.p : (void*)out; g.ldc = N;
+    if (rln) {
+        g.out2 = (half_t*)c->qkv.p; g.stats = (float*)c->cq.p; g.stats_ld = sld;
+        g.mu = (float*)c->cq.p + (size_t)rup(M, 256) * 2 * sld;
+        HG_HIP(hipMemsetAsync((void*)g.mu, 0, (size_t)M * 4, s));
+    }
     hipError_t e;
     ProfScope ps(c, s, epi, M, N, K);
     if (kernel == 1) e = launch_gemm_simple(epi, g, s);

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
             ++l.r;
             int tm, tn;
             tile_of(slot + l.r * cpx, tm, tn);
-            l.soff = isA ? tm * BM * p.lda * 2 : tn * 256 * p.K * 2;
+            l.soff = (xmode & 1) ? 0 : (isA ? tm * BM * p.lda * 2 : tn * 256 * p.K * 2);   // mode 1: every tile reads tile 0
         }
         l.st = l.st == (NST - 1) * STAGE ? 0 : l.st + STAGE;      // stage of stream position g is g % NST
     };
@@ -154,11 +154,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
     // which the hardware also adds to the global address, so voff*[i] carry -1024 * i
     auto dma_A = [&](auto I) {
         constexpr int i = decltype(I)::value;
+        if (xmode & 64) return;   // timing experiment: no operand DMA
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (HG_LDS void*)(smem + lA.st + wave * GA * 1024), 16, voffA[i],
                                                  lA.soff + lA.kt * (BK * 2), i * 1024, 0);
     };
     auto dma_W = [&](auto I) {
         constexpr int i = decltype(I)::value;
+        if (xmode & 64) return;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (HG_LDS void*)(smem + lW.st + AB + wave * GW * 1024), 16, voffW[i],
                                                  lW.soff + lW.kt * (BK * 2), i * 1024, 0);
     };
@@ -205,6 +207,18 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
     f32x4 acc[2][2][2][2];
     auto mma = [&](auto HA) {
         constexpr int ha = decltype(HA)::value;
+        if (xmode & 2) {   // timing experiment: no MFMAs (operands kept live)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int f = 0; f < 2; ++f) asm volatile("" ::"v"(xa[f][ks]));
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                    for (int g2 = 0; g2 < 2; ++g2) asm volatile("" ::"v"(wb[hb][g2][ks]));
+            }
+            return;
+        }
         SEG_B(3);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
