@@ -264,7 +264,8 @@ __global__ __launch_bounds__(256, 2) void gemm_duo(const GemmArgs p, const int t
             // residual rows (+ bias) through a register pipeline DEPTH column groups deep: the fragment registers are
             // dead here, and a shallower pipeline exposes one HBM round trip per group (8 per tile: measured 53 k cycles
             // per tile against 13 k for the whole K loop of out_proj)
-            constexpr int DEPTH = RLN ? 4 : 5;             // 5 spills with the LayerNorm extras (row sums, centres)
+            // 5 spills with the LayerNorm extras (row sums, centres), 4 with the column scale of the adapter epilogue on top
+            constexpr int DEPTH = RLN ? (SCALED ? 3 : 4) : 5;
             f32x4 xr[8][4], bvv[8], scv[SCALED ? 8 : 1];
             const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
             auto fetch = [&](auto GG) {
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo(const GemmArgs p, const int t
                 __builtin_amdgcn_sched_barrier(0);
             };
             fetch(integral_constant<int, 0>{}); fetch(integral_constant<int, 1>{}); fetch(integral_constant<int, 2>{});
-            fetch(integral_constant<int, 3>{});
+            if constexpr (DEPTH > 3) fetch(integral_constant<int, 3>{});
             if constexpr (DEPTH > 4) fetch(integral_constant<int, 4>{});
             __builtin_amdgcn_sched_barrier(0);
             step(integral_constant<int, 0>{}); step(integral_constant<int, 1>{}); step(integral_constant<int, 2>{});

@@ -848,9 +848,11 @@ hipError_t launch_gemm_ring(int epi, const GemmArgs& a, hipStream_t s) {
     if (!big && force_big != 3 && !lnc && gemm_ring2_ok(a)) return launch_gemm_ring2(epi, a, s);   // 128x256, two-phase
     // 256x256 tiles run two phases per K-tile (32 MFMAs per segment): -4..8 % vs four phases; HG_RING_PH2=0 = four
     static const bool ph2 = []() { const char* e = getenv("HG_RING_PH2"); return e ? atoi(e) != 0 : true; }();
+    // ... except with the residual epilogues: their rolling window does not fit beside the two-phase loop's fragment
+    // registers (9-21 spilled VGPRs, 4-10 % slower than four phases)
 #define HG_RING(E)                                                         \
     case E:                                                                \
-        return big ? (ph2 ? launch_ring_t<4, E, true>(a, s) : launch_ring_t<4, E, false>(a, s)) : launch_ring_t<2, E, false>(a, s)
+        return big ? (ph2 && !resid ? launch_ring_t<4, E, true>(a, s) : launch_ring_t<4, E, false>(a, s)) : launch_ring_t<2, E, false>(a, s)
     switch (epi) {
         HG_RING(EPI_BIAS_F16);
         HG_RING(EPI_BIAS_QGELU_F16);
@@ -862,8 +864,7 @@ hipError_t launch_gemm_ring(int epi, const GemmArgs& a, hipStream_t s) {
         HG_RING(EPI_SCALE_RESID_F32);
         HG_RING(EPI_LN_BIAS_F16);
         HG_RING(EPI_LN_BIAS_QGELU_F16);
-        case EPI_RESID_LN_F32:
-            return ph2 ? launch_ring_t<4, EPI_RESID_LN_F32, true>(a, s) : launch_ring_t<4, EPI_RESID_LN_F32, false>(a, s);
+        case EPI_RESID_LN_F32: return launch_ring_t<4, EPI_RESID_LN_F32, false>(a, s);
         default: return hipErrorInvalidValue;
     }
 #undef HG_RING
