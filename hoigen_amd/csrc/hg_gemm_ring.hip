@@ -66,7 +66,7 @@ template <int MF, int EPI, bool PH2>
 __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int tiles_n, const int n_tiles,
                                                     const unsigned a_bytes, const int mode, const int gsz) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins (buffer resources, LDS DMA): host sees just the stub
-    // timing-experiment switches (HG_RING_MODE bits 1 locality, 2 no MFMA, 4 no epilogue, 8 no stagger, 32 no fragment reads, 64 no operand DMA, 16 coalesced
+    // timing-experiment switches (HG_RING_MODE bits 1 locality, 2 no MFMA, 4 no epilogue, 8 no stagger, 32 no fragment reads, 64 no operand DMA, 128 no fp16 stores, 16 coalesced
     // stores) exist only in a -DHG_EXPERIMENTS build: run-time branches in the K loop cost several per cent
 #ifdef HG_EXPERIMENTS
     const int xmode = mode;
@@ -82,7 +82,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     constexpr bool RLN = (EPI == EPI_RESID_LN_F32);    // residual + centred fp16 copy + LayerNorm statistics (MF = 4)
     constexpr bool RESID = (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_SCALE_RESID_F32 || RLN);
     // epilogue store instructions per wave (vmcnt immediates are 6 bits: anything above is clamped, i.e. stricter)
-    constexpr int E_RAW = RLN ? 8 * MF + 4 * MF + 2 * MF : 8 * MF;
+    // (fp16 outputs leave as paired 16-byte stores: half as many; counting too many here would let the first waits of
+    // the next tile pass before its operands have landed)
+    constexpr bool F16_STORES = (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_BIAS_RELU_F16 ||
+                                 EPI == EPI_LN_BIAS_F16 || EPI == EPI_LN_BIAS_QGELU_F16);
+    constexpr int E_RAW = RLN ? 8 * MF + 4 * MF + 2 * MF : (F16_STORES ? 4 * MF : 8 * MF);
     constexpr int E = E_RAW > 52 ? 52 : E_RAW;
     // RESID at MF = 2: the residual rows are fetched one K-tile before the epilogue (64 spare VGPRs)
     constexpr bool XPRE = RESID && MF == 2;
@@ -351,10 +355,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     t_all = __builtin_amdgcn_s_memtime();
 #endif
     int g = 0;
+    // the previous tile lay inside M, i.e. issued every one of its E epilogue stores (a ragged tile may skip store
+    // instructions whose rows are all masked: the waits that follow it then do not allow for any)
+    bool prev_full = false;
     for (int r = 0; r < my_tiles; ++r) {
         int tm, tn;
         tile_of(slot + r * cpx, tm, tn);
         const int m0 = tm * BM, n0 = tn * 256;
+        const bool post_ok = prev_full;
+        prev_full = m0 + BM <= p.M;
         zero_acc();
         f32x4 xres[XPRE ? 2 : 1][XPRE ? 2 : 1][XPRE ? MF : 1][XPRE ? 2 : 1];
         // rolling residual window (ROLL): chunk c = ((ha * MF + f) * 2 + hb) * 2 + g2 is this lane's f32x4 of row
@@ -378,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
         auto ph2_ktile = [&](auto KIND_T) {
             constexpr int KIND = decltype(KIND_T)::value;
             const int buf = (g & 1) * STAGE;
-            const bool post = r > 0;
+            const bool post = post_ok;
             const bool more = KIND < 2 || r + 1 < my_tiles;      // a K-tile two positions ahead exists
             (void)post; (void)more;
             // Two phases per K-tile (32 MFMAs per segment, half the barriers):
@@ -458,7 +467,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
         for (int kt = 0; kt < nk; ++kt, ++g) {
             const int buf = (g & 1) * STAGE;
             const bool more = g + 2 < S;          // a K-tile two positions ahead exists
-            const bool post = r > 0;               // epilogue stores of the previous tile may still be pending
+            const bool post = post_ok;             // epilogue stores of the previous tile may still be pending
             const bool xl = (XPRE || ROLL) && kt == nk - 1;  // residual rows are fetched during the last K-tile
             // ---------------- P1: fetch A0(t), W0(t); refill A1(t+1); then quadrant (0,0)
             read_A(0, buf);
@@ -614,6 +623,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                                 const int idx = ((ha * (MF / 2) + f / 2) * 2 + hb) * 2 + g2;
                                 const int rr = m0 + (wave * (4 * MF) + idx) * 2 + (lane >> 5);
                                 if (rr < p.M) *reinterpret_cast<u32x4*>(outp + (size_t)rr * p.ldc + n0 + (lane & 31) * 8) = o;
+                            } else if (xmode & 128) {   // timing experiment: epilogue arithmetic without the stores
+                                asm volatile("" ::"v"(o));
                             } else
                             if (INTERIOR || m < p.M)
                                 *reinterpret_cast<u32x4*>(outp + (size_t)m * p.ldc + nb + 4 * (q & ~1)) = o;

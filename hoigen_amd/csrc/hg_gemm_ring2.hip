@@ -274,10 +274,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
     t_all = __builtin_amdgcn_s_memtime();
 #endif
     int g = 0, stg = 0;                        // K-tile position in the stream and its LDS stage (g % NST)
+    // the previous tile lay inside M, i.e. issued every one of its E epilogue stores (a ragged tile may skip store
+    // instructions whose rows are all masked: the waits that follow it then do not allow for any)
+    bool prev_full = false;
     for (int r = 0; r < my_tiles; ++r) {
         int tm, tn;
         tile_of(slot + r * cpx, tm, tn);
         const int m0 = tm * BM, n0 = tn * 256;
+        const bool post_ok = prev_full;
+        prev_full = m0 + BM <= p.M;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
             if (KIND < 2 || more) issue_W(std::integral_constant<int, KIND == 2 ? 1 : 0>{});   // K-tile g+3 exists
             SEG_B(0);
             if constexpr (KIND == 0) wait_vm<NWT>();
-            else if constexpr (KIND == 1) { if (r > 0) wait_vm<NWT + E>(); else wait_vm<NWT>(); }
+            else if constexpr (KIND == 1) { if (post_ok) wait_vm<NWT + E>(); else wait_vm<NWT>(); }
             else if constexpr (KIND == 4) { if (more) wait_vm<NWT + R>(); }       // no successor: nothing to wait for
             else { if (more) wait_vm<NWT>(); else wait_vm<0>(); }
             SEG_E(0);
