@@ -64,7 +64,7 @@ namespace hg {
 
 template <int MF, int EPI, bool PH2>
 __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int tiles_n, const int n_tiles,
-                                                    const unsigned a_bytes, const int mode, const int gsz) {
+                                                    const unsigned a_bytes, const int mode, const int gszx) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins (buffer resources, LDS DMA): host sees just the stub
     // timing-experiment switches (HG_RING_MODE bits 1 locality, 2 no MFMA, 4 no epilogue, 8 no stagger, 32 no fragment reads, 64 no operand DMA, 128 no fp16 stores, 16 coalesced
     // stores) exist only in a -DHG_EXPERIMENTS build: run-time branches in the K loop cost several per cent
@@ -122,8 +122,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     const int xbase = xcd_ok ? (bid & 7) * T8 : 0;
     const int xend = (xbase + T8 < n_tiles) ? xbase + T8 : n_tiles;
     const int slot = xbase + (xcd_ok ? (bid >> 3) : bid);          // first list item of this workgroup
-    const int my_tiles = slot < xend ? (xend - slot + cpx - 1) / cpx : 0;
+    int my_tiles = slot < xend ? (xend - slot + cpx - 1) / cpx : 0;
     const int tiles_m_all = n_tiles / tiles_n;
+    const int gsz = gszx & 0xFFFF;
     const int ngf = tiles_n / gsz, grem = tiles_n - ngf * gsz, per_grp = tiles_m_all * gsz;
     auto tile_of = [&](int item, int& tm, int& tn) {
         if (item < ngf * per_grp) {
@@ -151,6 +152,22 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             while ((long long)(__builtin_amdgcn_s_memtime() - t0) < d) __builtin_amdgcn_s_sleep(32);
         }
     }
+    // Phase shift (fp16-output kernels, two-phase loop): every second workgroup of an XCD starts with the TOP HALF of
+    // its first tile (rows 0..BM/2-1: the PB quadrants are skipped) and ends with that tile's BOTTOM HALF.  Same work,
+    // but its epilogues fall into the middle of its neighbours' K loops: the store bursts (128 KiB per CU that HBM
+    // absorbs at 10 B/clk/CU while the wave's next DMA instructions queue behind the stores) no longer come from all
+    // 256 CUs at once.  half: 0 full tile, 1 top half, 2 bottom half.
+    const bool shifted = PH2 && F16_STORES && (gszx >> 16) != 0 && ((bid >> 3) & 1) && my_tiles >= 2;
+    if (shifted) ++my_tiles;
+    auto seq_tile = [&](int rr, int& tm, int& tn) -> int {
+        int item = slot + rr * cpx, half = 0;
+        if (shifted) {
+            if (rr == 0) { item = slot; half = 1; }
+            else if (rr == my_tiles - 1) { item = slot; half = 2; }
+        }
+        tile_of(item, tm, tn);
+        return half;
+    };
     const int S = my_tiles * nk;                               // K-tiles in this workgroup's stream
 
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
@@ -188,8 +205,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             ld_kt = 0;
             ++ld_r;
             int tm, tn;
-            tile_of(slot + ld_r * cpx, tm, tn);
-            ld_sA = (xmode & 1) ? 0 : tm * BM * p.lda * 2;     // mode 1 (timing experiment): every tile reads tile 0
+            const int half = seq_tile(ld_r, tm, tn);
+            ld_sA = (xmode & 1) ? 0 : (tm * BM + (half == 2 ? BM / 2 : 0)) * p.lda * 2;   // mode 1 (timing experiment): every tile reads tile 0
             ld_sW = (xmode & 1) ? 0 : tn * 256 * p.K * 2;
         }
         ld_buf = (ld_g & 1) * STAGE;
@@ -360,10 +377,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     bool prev_full = false;
     for (int r = 0; r < my_tiles; ++r) {
         int tm, tn;
-        tile_of(slot + r * cpx, tm, tn);
-        const int m0 = tm * BM, n0 = tn * 256;
+        const int half = seq_tile(r, tm, tn);
+        const bool hf = half != 0;                          // half tile: rows m0 .. m0 + BM/2 - 1 only
+        const int m0 = tm * BM + (half == 2 ? BM / 2 : 0), n0 = tn * 256;
         const bool post_ok = prev_full;
-        prev_full = m0 + BM <= p.M;
+        prev_full = !hf && m0 + BM <= p.M;
         zero_acc();
         f32x4 xres[XPRE ? 2 : 1][XPRE ? 2 : 1][XPRE ? MF : 1][XPRE ? 2 : 1];
         // rolling residual window (ROLL): chunk c = ((ha * MF + f) * 2 + hb) * 2 + g2 is this lane's f32x4 of row
@@ -440,7 +458,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             mma(I0{}, I0{});
             mma(I0{}, I1{});
             sync_mma();
-            read_A(1, buf);
+            if (!hf) read_A(1, buf);
             if (KIND < 2 || more) { ld_advance(std::integral_constant<int, KIND == 2 ? 1 : 0>{}); issue_A(0, 0, GA); issue_W(0, 0, GB); issue_W(1, 0, GB); }
             SEG_B(0);
             if constexpr (KIND == 0) wait_vm<NP>();
@@ -449,8 +467,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             else { if (more) wait_vm<NP + R>(); else wait_vm<0>(); }
             SEG_E(0);
             sync_fetch();
-            mma(I1{}, I1{});
-            mma(I1{}, I0{});
+            if (!hf) {
+                mma(I1{}, I1{});
+                mma(I1{}, I0{});
+            }
             sync_mma();
             ++g;
         };
@@ -575,32 +595,49 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             f32x4 gk = {0.f, 0.f, 0.f, 0.f};
             if constexpr (EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_LN_BIAS_QGELU_F16) gk = quick_gelu_consts();
             (void)gk;
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            // bias (and folded-weight column sums) of this wave's four 16-column groups: read once per tile (the
+            // fragment registers are dead here); a wave spends ~5 cycles per instruction it issues, so the epilogue is
+            // written for instruction count: packed adds, v_cvt_pk_f16_f32 on pairs, one row pointer per row pair
+            f32x4 bv[2][2], cv[2][2];
 #pragma unroll
-            for (int ha = 0; ha < 2; ++ha)
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const int nq = n0 + hb * 128 + wn * 32 + g2 * 16 + 4 * q;
+                    bv[hb][g2] = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + nq * 4);
+                    if constexpr (LNC) cv[hb][g2] = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + p.N * 4 + nq * 4);
+                    else cv[hb][g2] = bv[hb][g2];
+                }
+            auto cvt2 = [](float a, float b) {      // RNE, one v_cvt_pk_f16_f32
+                const half2v h = __builtin_convertvector(f32x2{a, b}, half2v);
+                return __builtin_bit_cast(unsigned, h);
+            };
+#pragma unroll
+            for (int ha = 0; ha < 2; ++ha) {
+                if (ha == 1 && hf) break;                       // half tile: the A1 rows were not computed
 #pragma unroll
                 for (int f = 0; f < MF; f += 2) {
                     const int mX = m0 + ha * (BM / 2) + wm * MF * 16 + f * 16 + (lane & 15);
                     const int m = mX + ((q & 1) ? 16 : 0);
-                    typedef float f32x2 __attribute__((ext_vector_type(2)));
                     f32x2 mrx = {0.f, 1.f}, mry = {0.f, 1.f};       // (mean, rstd) of rows mX and mX + 16
                     if constexpr (LNC) {
                         mrx = *reinterpret_cast<const f32x2*>(smem + MR_OFF + (mX - m0) * 8);
                         mry = *reinterpret_cast<const f32x2*>(smem + MR_OFF + (mX - m0 + 16) * 8);
                     }
+                    half_t* rowp = outp + (size_t)m * p.ldc + n0 + wn * 32 + 4 * (q & ~1);
 #pragma unroll
                     for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
                         for (int g2 = 0; g2 < 2; ++g2) {
-                            const int nb = n0 + hb * 128 + wn * 32 + g2 * 16;
-                            const f32x4 bv = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (nb + 4 * q) * 4);
                             f32x4 vx, vy;
                             if constexpr (LNC) {   // rstd * (acc - mean * cs) + bias'
-                                const f32x4 cv = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + p.N * 4 + (nb + 4 * q) * 4);
-                                vx = (acc[ha][hb][f][g2] - cv * mrx[0]) * mrx[1] + bv;
-                                vy = (acc[ha][hb][f + 1][g2] - cv * mry[0]) * mry[1] + bv;
+                                vx = (acc[ha][hb][f][g2] - cv[hb][g2] * mrx[0]) * mrx[1] + bv[hb][g2];
+                                vy = (acc[ha][hb][f + 1][g2] - cv[hb][g2] * mry[0]) * mry[1] + bv[hb][g2];
                             } else {
-                                vx = acc[ha][hb][f][g2] + bv;
-                                vy = acc[ha][hb][f + 1][g2] + bv;
+                                vx = acc[ha][hb][f][g2] + bv[hb][g2];
+                                vy = acc[ha][hb][f + 1][g2] + bv[hb][g2];
                             }
                             if constexpr (EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_LN_BIAS_QGELU_F16) {
                                 vx = quick_gelu4(vx, gk);
@@ -610,14 +647,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) { vx[r] = fmaxf(vx[r], 0.f); vy[r] = fmaxf(vy[r], 0.f); }
                             }
-                            half4 hx, hy;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) { hx[r] = (half_t)vx[r]; hy[r] = (half_t)vy[r]; }
-                            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                            const u32x2 ux = __builtin_bit_cast(u32x2, hx), uy = __builtin_bit_cast(u32x2, hy);
-                            const auto s0 = __builtin_amdgcn_permlane16_swap(ux[0], uy[0], false, false);
-                            const auto s1 = __builtin_amdgcn_permlane16_swap(ux[1], uy[1], false, false);
-                            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                            const auto s0 = __builtin_amdgcn_permlane16_swap(cvt2(vx[0], vx[1]), cvt2(vy[0], vy[1]), false, false);
+                            const auto s1 = __builtin_amdgcn_permlane16_swap(cvt2(vx[2], vx[3]), cvt2(vy[2], vy[3]), false, false);
                             const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
                             if (xmode & 16) {   // timing experiment: lane-linear (fully coalesced, WRONG) addresses
                                 const int idx = ((ha * (MF / 2) + f / 2) * 2 + hb) * 2 + g2;
@@ -627,11 +658,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                                 asm volatile("" ::"v"(o));
                             } else
                             if (INTERIOR || m < p.M)
-                                *reinterpret_cast<u32x4*>(outp + (size_t)m * p.ldc + nb + 4 * (q & ~1)) = o;
+                                *reinterpret_cast<u32x4*>(rowp + hb * 128 + g2 * 16) = o;
                         }
                 }
+            }
             };
-            if (m0 + BM <= p.M) f16_epilogue(std::true_type{});
+            if (m0 + (hf ? BM / 2 : BM) <= p.M) f16_epilogue(std::true_type{});
             else f16_epilogue(std::false_type{});
         } else if constexpr (ROLL) {
             // residual epilogue through the rolling window: chunk c is consumed, stored, and its window slot is
@@ -791,6 +823,9 @@ static hipError_t launch_ring_t(const GemmArgs& a, hipStream_t s) {
         const int ngroups = (tiles_n + gsz - 1) / gsz;
         gsz = (tiles_n + ngroups - 1) / ngroups;
     }
+    // phase-shifted half tiles (see the kernel): HG_RING_HALF=0 turns them off
+    static const int half_on = []() { const char* e = getenv("HG_RING_HALF"); return e ? atoi(e) : 1; }();
+    gsz |= (half_on ? 1 : 0) << 16;
 #ifdef HG_STAMPS
     if (getenv("HG_STAMPS")) {
         const size_t n = (size_t)grid * 8 * 16;
