@@ -64,7 +64,7 @@ namespace hg {
 
 template <int MF, int EPI, bool PH2>
 __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int tiles_n, const int n_tiles,
-                                                    const unsigned a_bytes, const int mode, const int gszx) {
+                                                    const unsigned a_bytes, const int mode, const int gsz) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins (buffer resources, LDS DMA): host sees just the stub
     // timing-experiment switches (HG_RING_MODE bits 1 locality, 2 no MFMA, 4 no epilogue, 8 no stagger, 32 no fragment reads, 64 no operand DMA, 128 no fp16 stores, 16 coalesced
     // stores) exist only in a -DHG_EXPERIMENTS build: run-time branches in the K loop cost several per cent
@@ -104,6 +104,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
 #ifdef HG_STAMPS
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_beg = 0, t_all = 0;
 #endif
+    // HG_TRACE build: time stamps (s_memtime) of one wave around the boundary between its second and third tile: after
+    // the last K-tiles of tile 1, after its epilogue, after the first K-tiles of tile 2 (tools/gpu_ring_trace.sh)
+#ifdef HG_TRACE
+    unsigned long long ttr[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int ttn = 0;
+#define HG_TR(cond) do { if ((cond) && ttn < 16) { ttr[ttn] = __builtin_amdgcn_s_memtime(); ++ttn; } } while (0)
+#else
+#define HG_TR(cond) do {} while (0)
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -122,9 +131,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     const int xbase = xcd_ok ? (bid & 7) * T8 : 0;
     const int xend = (xbase + T8 < n_tiles) ? xbase + T8 : n_tiles;
     const int slot = xbase + (xcd_ok ? (bid >> 3) : bid);          // first list item of this workgroup
-    int my_tiles = slot < xend ? (xend - slot + cpx - 1) / cpx : 0;
+    const int my_tiles = slot < xend ? (xend - slot + cpx - 1) / cpx : 0;
     const int tiles_m_all = n_tiles / tiles_n;
-    const int gsz = gszx & 0xFFFF;
     const int ngf = tiles_n / gsz, grem = tiles_n - ngf * gsz, per_grp = tiles_m_all * gsz;
     auto tile_of = [&](int item, int& tm, int& tn) {
         if (item < ngf * per_grp) {
@@ -152,22 +160,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             while ((long long)(__builtin_amdgcn_s_memtime() - t0) < d) __builtin_amdgcn_s_sleep(32);
         }
     }
-    // Phase shift (fp16-output kernels, two-phase loop): every second workgroup of an XCD starts with the TOP HALF of
-    // its first tile (rows 0..BM/2-1: the PB quadrants are skipped) and ends with that tile's BOTTOM HALF.  Same work,
-    // but its epilogues fall into the middle of its neighbours' K loops: the store bursts (128 KiB per CU that HBM
-    // absorbs at 10 B/clk/CU while the wave's next DMA instructions queue behind the stores) no longer come from all
-    // 256 CUs at once.  half: 0 full tile, 1 top half, 2 bottom half.
-    const bool shifted = PH2 && F16_STORES && (gszx >> 16) != 0 && ((bid >> 3) & 1) && my_tiles >= 2;
-    if (shifted) ++my_tiles;
-    auto seq_tile = [&](int rr, int& tm, int& tn) -> int {
-        int item = slot + rr * cpx, half = 0;
-        if (shifted) {
-            if (rr == 0) { item = slot; half = 1; }
-            else if (rr == my_tiles - 1) { item = slot; half = 2; }
-        }
-        tile_of(item, tm, tn);
-        return half;
-    };
     const int S = my_tiles * nk;                               // K-tiles in this workgroup's stream
 
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
@@ -205,8 +197,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             ld_kt = 0;
             ++ld_r;
             int tm, tn;
-            const int half = seq_tile(ld_r, tm, tn);
-            ld_sA = (xmode & 1) ? 0 : (tm * BM + (half == 2 ? BM / 2 : 0)) * p.lda * 2;   // mode 1 (timing experiment): every tile reads tile 0
+            tile_of(slot + ld_r * cpx, tm, tn);
+            ld_sA = (xmode & 1) ? 0 : tm * BM * p.lda * 2;     // mode 1 (timing experiment): every tile reads tile 0
             ld_sW = (xmode & 1) ? 0 : tn * 256 * p.K * 2;
         }
         ld_buf = (ld_g & 1) * STAGE;
@@ -377,11 +369,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     bool prev_full = false;
     for (int r = 0; r < my_tiles; ++r) {
         int tm, tn;
-        const int half = seq_tile(r, tm, tn);
-        const bool hf = half != 0;                          // half tile: rows m0 .. m0 + BM/2 - 1 only
-        const int m0 = tm * BM + (half == 2 ? BM / 2 : 0), n0 = tn * 256;
+        tile_of(slot + r * cpx, tm, tn);
+        const int m0 = tm * BM, n0 = tn * 256;
         const bool post_ok = prev_full;
-        prev_full = !hf && m0 + BM <= p.M;
+        prev_full = m0 + BM <= p.M;
         zero_acc();
         f32x4 xres[XPRE ? 2 : 1][XPRE ? 2 : 1][XPRE ? MF : 1][XPRE ? 2 : 1];
         // rolling residual window (ROLL): chunk c = ((ha * MF + f) * 2 + hb) * 2 + g2 is this lane's f32x4 of row
@@ -458,7 +449,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             mma(I0{}, I0{});
             mma(I0{}, I1{});
             sync_mma();
-            if (!hf) read_A(1, buf);
+            read_A(1, buf);
             if (KIND < 2 || more) { ld_advance(std::integral_constant<int, KIND == 2 ? 1 : 0>{}); issue_A(0, 0, GA); issue_W(0, 0, GB); issue_W(1, 0, GB); }
             SEG_B(0);
             if constexpr (KIND == 0) wait_vm<NP>();
@@ -467,10 +458,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             else { if (more) wait_vm<NP + R>(); else wait_vm<0>(); }
             SEG_E(0);
             sync_fetch();
-            if (!hf) {
-                mma(I1{}, I1{});
-                mma(I1{}, I0{});
-            }
+            mma(I1{}, I1{});
+            mma(I1{}, I0{});
             sync_mma();
             ++g;
         };
@@ -480,9 +469,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             using K2 = std::integral_constant<int, 2>;
             using K3 = std::integral_constant<int, 3>;
             ph2_ktile(K1{});
-            for (int kt = 1; kt < nk - 2; ++kt) ph2_ktile(K0{});
+            HG_TR(r == 2);
+            for (int kt = 1; kt < nk - 2; ++kt) {
+                ph2_ktile(K0{});
+                HG_TR((r == 1 && kt >= nk - 5) || (r == 2 && kt <= 4));
+            }
             ph2_ktile(K2{});
+            HG_TR(r == 1);
             ph2_ktile(K3{});
+            HG_TR(r == 1);
         } else {
         for (int kt = 0; kt < nk; ++kt, ++g) {
             const int buf = (g & 1) * STAGE;
@@ -615,8 +610,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                 return __builtin_bit_cast(unsigned, h);
             };
 #pragma unroll
-            for (int ha = 0; ha < 2; ++ha) {
-                if (ha == 1 && hf) break;                       // half tile: the A1 rows were not computed
+            for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
                 for (int f = 0; f < MF; f += 2) {
                     const int mX = m0 + ha * (BM / 2) + wm * MF * 16 + f * 16 + (lane & 15);
@@ -661,9 +655,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                                 *reinterpret_cast<u32x4*>(rowp + hb * 128 + g2 * 16) = o;
                         }
                 }
-            }
             };
-            if (m0 + (hf ? BM / 2 : BM) <= p.M) f16_epilogue(std::true_type{});
+            if (m0 + BM <= p.M) f16_epilogue(std::true_type{});
             else f16_epilogue(std::false_type{});
         } else if constexpr (ROLL) {
             // residual epilogue through the rolling window: chunk c is consumed, stored, and its window slot is
@@ -765,7 +758,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             }
         }
         SEG_E(7);
+        HG_TR(r == 1);
     }
+#ifdef HG_TRACE
+    if (p.dbg && lane == 0) {
+        unsigned long long* d = p.dbg + (size_t)(blockIdx.x * 8 + wave) * 16;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) d[k] = ttr[k];
+    }
+#endif
 #ifdef HG_STAMPS
     if (p.dbg && lane == 0) {
         unsigned long long* d = p.dbg + (size_t)(blockIdx.x * 8 + wave) * 16;
@@ -823,9 +824,35 @@ static hipError_t launch_ring_t(const GemmArgs& a, hipStream_t s) {
         const int ngroups = (tiles_n + gsz - 1) / gsz;
         gsz = (tiles_n + ngroups - 1) / ngroups;
     }
-    // phase-shifted half tiles (see the kernel): HG_RING_HALF=0 turns them off
-    static const int half_on = []() { const char* e = getenv("HG_RING_HALF"); return e ? atoi(e) : 1; }();
-    gsz |= (half_on ? 1 : 0) << 16;
+#ifdef HG_TRACE
+    if (getenv("HG_TRACE")) {
+        const size_t n = (size_t)grid * 8 * 16;
+        unsigned long long* d = nullptr;
+        if (hipMalloc(&d, n * 8) != hipSuccess) return hipErrorOutOfMemory;
+        hipMemsetAsync(d, 0, n * 8, s);
+        GemmArgs b = a;
+        b.dbg = d;
+        hipLaunchKernelGGL((gemm_ring<MF, EPI, PH2>), dim3(grid), dim3(512), LDS, s, b, tiles_n, n_tiles, (unsigned)a_bytes, mode, gsz);
+        hipStreamSynchronize(s);
+        unsigned long long* h = (unsigned long long*)malloc(n * 8);
+        hipMemcpy(h, d, n * 8, hipMemcpyDeviceToHost);
+        for (int blk : {0, 9, 130}) {
+            if (blk >= grid) continue;
+            const unsigned long long t0 = h[(size_t)(blk * 8) * 16];
+            for (int w : {0, 4}) {
+                fprintf(stderr, "[trace] ring<%d,%d> N=%d K=%d block %d wave %d:", MF, EPI, a.N, a.K, blk, w);
+                for (int k = 0; k < 16; ++k) {
+                    const unsigned long long t = h[(size_t)(blk * 8 + w) * 16 + k];
+                    if (t) fprintf(stderr, " %lld", (long long)(t - t0));
+                }
+                fprintf(stderr, "\n");
+            }
+        }
+        free(h);
+        hipFree(d);
+        return hipGetLastError();
+    }
+#endif
 #ifdef HG_STAMPS
     if (getenv("HG_STAMPS")) {
         const size_t n = (size_t)grid * 8 * 16;
