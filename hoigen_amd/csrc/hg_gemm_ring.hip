@@ -805,7 +805,10 @@ static hipError_t launch_ring_t(const GemmArgs& a, hipStream_t s) {
     }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / 256;
     const int n_tiles = tiles_m * tiles_n;
-    const int grid = n_tiles < n_cu ? n_tiles : n_cu;
+    int grid = n_tiles < n_cu ? n_tiles : n_cu;
+#ifdef HG_EXPERIMENTS
+    if (const char* e = getenv("HG_RING_GRID")) grid = atoi(e) < grid ? atoi(e) : grid;   // fewer CUs: how does a tile's time change?
+#endif
     const size_t a_bytes = (size_t)tiles_m * BM * a.lda * 2;      // A is allocated with rows padded to 256
     static const int mode = []() {
         const char* e = getenv("HG_RING_MODE");
