@@ -11,7 +11,8 @@ from hoigen_amd import _lib
 h = _lib.lib().hg_create(0)
 M = int(os.environ.get("M", 197 * 256))
 shapes = {"cproj": (768, 3072, 3), "outproj": (768, 768, 3), "qkv": (2304, 768, 0), "cfc": (3072, 768, 1),
-          "cproj4": (768, 3072, 4), "outproj4": (768, 768, 4), "cproj10": (768, 3072, 10), "outproj10": (768, 768, 10)}
+          "cproj4": (768, 3072, 4), "outproj4": (768, 768, 4), "cproj10": (768, 3072, 10), "outproj10": (768, 768, 10),
+          "vae1": (2048, 512, 2), "vae3": (4096, 512, 2)}
 kernels = [int(k) for k in os.environ.get("KERNELS", "2 3").split()]
 rounds = int(os.environ.get("ROUNDS", 5))
 for name in os.environ.get("SHAPES", "outproj cproj qkv cfc").split():
