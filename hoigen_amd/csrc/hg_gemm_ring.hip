@@ -66,8 +66,9 @@ template <int MF, int EPI, bool PH2>
 __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int tiles_n, const int n_tiles,
                                                     const unsigned a_bytes, const int mode, const int gsz) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins (buffer resources, LDS DMA): host sees just the stub
-    // timing-experiment switches (HG_RING_MODE bits 1 locality, 2 no MFMA, 4 no epilogue, 8 no stagger, 32 no fragment reads, 64 no operand DMA, 128 no fp16 stores, 16 coalesced
-    // stores) exist only in a -DHG_EXPERIMENTS build: run-time branches in the K loop cost several per cent
+    // timing-experiment switches (HG_RING_MODE bits 1 locality, 2 no MFMA, 4 no epilogue, 8 no stagger, 32 no fragment
+    // reads, 64 no operand DMA, 128 no fp16 stores) exist only in a -DHG_EXPERIMENTS build: run-time branches in the K
+    // loop cost several per cent
 #ifdef HG_EXPERIMENTS
     const int xmode = mode;
 #else
@@ -182,7 +183,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
         for (int i = 0; i < GB; ++i) {
             const int row = (wave * GB + i) * 8 + (lane >> 3);
             const int c = (lane & 7) ^ ((row >> 1) & 7);
-            voffW[h][i] = (h * 128 + row) * p.K * 2 + c * 16 - i * 1024;
+            // fp16-output kernels: LDS row `row` of W half h holds output column (row/32)*64 + 16*((row%16)/4) +
+            // 4*(2h + (row%32)/16) + row%4 of the tile, so that wave wn owns the 64 CONSECUTIVE columns wn*64.. and a
+            // lane's four MFMA blocks (hb, g2) hold 16 consecutive ones: rows leave as whole 128-byte lines (epilogue)
+            const int src = F16_STORES ? (row >> 5) * 64 + 16 * ((row & 15) >> 2) + 4 * (2 * h + ((row & 31) >> 4)) + (row & 3)
+                                       : h * 128 + row;
+            voffW[h][i] = src * p.K * 2 + c * 16 - i * 1024;
         }
     }
     // ---- load-stream state (wave-uniform): position ld_g, its tile origin and K offset
@@ -585,75 +591,72 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             // tiles that lie entirely inside M (all of them at M = 197 * 256) skip the per-store row masks
             auto f16_epilogue = [&](auto INTERIOR_T) {
             constexpr bool INTERIOR = decltype(INTERIOR_T)::value;
-            const int q = lane >> 4;
+            const int q = lane >> 4, r16 = lane & 15;
             half_t* outp = reinterpret_cast<half_t*>(p.out);
             f32x4 gk = {0.f, 0.f, 0.f, 0.f};
             if constexpr (EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_LN_BIAS_QGELU_F16) gk = quick_gelu_consts();
             (void)gk;
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            // bias (and folded-weight column sums) of this wave's four 16-column groups: read once per tile (the
-            // fragment registers are dead here); a wave spends ~5 cycles per instruction it issues, so the epilogue is
-            // written for instruction count: packed adds, v_cvt_pk_f16_f32 on pairs, one row pointer per row pair
-            f32x4 bv[2][2], cv[2][2];
+            // Column map (see voffW): acc[ha][hb][f][g2] of lane (r16, q) = row ha*BM/2 + wm*MF*16 + f*16 + r16, columns
+            // wn*64 + 16q + 4(2hb + g2) + 0..3: the lane's four blocks are 16 consecutive columns = 32 bytes of fp16,
+            // a row's 64 columns sit in its four q lanes.  A store instruction that touches 32 partial lines holds the
+            // CU's store path for 72 cycles, one that writes 8 whole lines for 17 (tools/ubench/store_path.hip), so rows
+            // r16 and r16 ^ 8 trade halves through a row_ror:8 DPP move: lanes r16 < 8 keep columns +0..7 and receive
+            // +0..7 of row r16 + 8, lanes r16 >= 8 receive +8..15 of row r16 - 8 and keep their own +8..15; the first
+            // store then writes rows 0..7 of the 16-row block and the second rows 8..15, eight lanes (128 B) per row.
+            // Bias (and folded-weight column sums) of the lane's 16 columns are read once per tile.
+            f32x4 bv[4], cv[4];
+            const int nq = n0 + wn * 64 + 16 * q;
 #pragma unroll
-            for (int hb = 0; hb < 2; ++hb)
-#pragma unroll
-                for (int g2 = 0; g2 < 2; ++g2) {
-                    const int nq = n0 + hb * 128 + wn * 32 + g2 * 16 + 4 * q;
-                    bv[hb][g2] = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + nq * 4);
-                    if constexpr (LNC) cv[hb][g2] = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + p.N * 4 + nq * 4);
-                    else cv[hb][g2] = bv[hb][g2];
-                }
+            for (int b4 = 0; b4 < 4; ++b4) {
+                bv[b4] = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (nq + 4 * b4) * 4);
+                if constexpr (LNC) cv[b4] = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + p.N * 4 + (nq + 4 * b4) * 4);
+                else cv[b4] = bv[b4];
+            }
             auto cvt2 = [](float a, float b) {      // RNE, one v_cvt_pk_f16_f32
                 const half2v h = __builtin_convertvector(f32x2{a, b}, half2v);
                 return __builtin_bit_cast(unsigned, h);
             };
+            const bool low = r16 < 8;
+            // byte offset of this lane's 16-byte piece inside a row: columns wn*64 + 8 * (2q + (r16 >> 3))
+            half_t* colp = outp + n0 + wn * 64 + 8 * (2 * q + (r16 >> 3));
 #pragma unroll
             for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
-                for (int f = 0; f < MF; f += 2) {
-                    const int mX = m0 + ha * (BM / 2) + wm * MF * 16 + f * 16 + (lane & 15);
-                    const int m = mX + ((q & 1) ? 16 : 0);
-                    f32x2 mrx = {0.f, 1.f}, mry = {0.f, 1.f};       // (mean, rstd) of rows mX and mX + 16
-                    if constexpr (LNC) {
-                        mrx = *reinterpret_cast<const f32x2*>(smem + MR_OFF + (mX - m0) * 8);
-                        mry = *reinterpret_cast<const f32x2*>(smem + MR_OFF + (mX - m0 + 16) * 8);
-                    }
-                    half_t* rowp = outp + (size_t)m * p.ldc + n0 + wn * 32 + 4 * (q & ~1);
+                for (int f = 0; f < MF; ++f) {
+                    const int mb = m0 + ha * (BM / 2) + wm * MF * 16 + f * 16;      // first row of the 16-row block
+                    f32x2 mr = {0.f, 1.f};                                           // (mean, rstd) of row mb + r16
+                    if constexpr (LNC) mr = *reinterpret_cast<const f32x2*>(smem + MR_OFF + (mb + r16 - m0) * 8);
+                    unsigned d[8];
 #pragma unroll
-                    for (int hb = 0; hb < 2; ++hb)
+                    for (int b4 = 0; b4 < 4; ++b4) {
+                        f32x4 v;
+                        if constexpr (LNC) v = (acc[ha][b4 >> 1][f][b4 & 1] - cv[b4] * mr[0]) * mr[1] + bv[b4];   // rstd * (acc - mean * cs) + bias'
+                        else v = acc[ha][b4 >> 1][f][b4 & 1] + bv[b4];
+                        if constexpr (EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_LN_BIAS_QGELU_F16) v = quick_gelu4(v, gk);
+                        if constexpr (EPI == EPI_BIAS_RELU_F16) {
 #pragma unroll
-                        for (int g2 = 0; g2 < 2; ++g2) {
-                            f32x4 vx, vy;
-                            if constexpr (LNC) {   // rstd * (acc - mean * cs) + bias'
-                                vx = (acc[ha][hb][f][g2] - cv[hb][g2] * mrx[0]) * mrx[1] + bv[hb][g2];
-                                vy = (acc[ha][hb][f + 1][g2] - cv[hb][g2] * mry[0]) * mry[1] + bv[hb][g2];
-                            } else {
-                                vx = acc[ha][hb][f][g2] + bv[hb][g2];
-                                vy = acc[ha][hb][f + 1][g2] + bv[hb][g2];
-                            }
-                            if constexpr (EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_LN_BIAS_QGELU_F16) {
-                                vx = quick_gelu4(vx, gk);
-                                vy = quick_gelu4(vy, gk);
-                            }
-                            if constexpr (EPI == EPI_BIAS_RELU_F16) {
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) { vx[r] = fmaxf(vx[r], 0.f); vy[r] = fmaxf(vy[r], 0.f); }
-                            }
-                            const auto s0 = __builtin_amdgcn_permlane16_swap(cvt2(vx[0], vx[1]), cvt2(vy[0], vy[1]), false, false);
-                            const auto s1 = __builtin_amdgcn_permlane16_swap(cvt2(vx[2], vx[3]), cvt2(vy[2], vy[3]), false, false);
-                            const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
-                            if (xmode & 16) {   // timing experiment: lane-linear (fully coalesced, WRONG) addresses
-                                const int idx = ((ha * (MF / 2) + f / 2) * 2 + hb) * 2 + g2;
-                                const int rr = m0 + (wave * (4 * MF) + idx) * 2 + (lane >> 5);
-                                if (rr < p.M) *reinterpret_cast<u32x4*>(outp + (size_t)rr * p.ldc + n0 + (lane & 31) * 8) = o;
-                            } else if (xmode & 128) {   // timing experiment: epilogue arithmetic without the stores
-                                asm volatile("" ::"v"(o));
-                            } else
-                            if (INTERIOR || m < p.M)
-                                *reinterpret_cast<u32x4*>(rowp + hb * 128 + g2 * 16) = o;
+                            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                         }
+                        d[2 * b4] = cvt2(v[0], v[1]);
+                        d[2 * b4 + 1] = cvt2(v[2], v[3]);
+                    }
+                    u32x4 st0, st1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned send = low ? d[4 + j] : d[j];
+                        const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0x128, 0xF, 0xF, false);   // row_ror:8
+                        st0[j] = low ? d[j] : recv;
+                        st1[j] = low ? recv : d[4 + j];
+                    }
+                    const int row0 = mb + (r16 & 7);
+                    if (xmode & 128) {   // timing experiment: epilogue arithmetic without the stores
+                        asm volatile("" ::"v"(st0), "v"(st1));
+                    } else {
+                        if (INTERIOR || row0 < p.M) *reinterpret_cast<u32x4*>(colp + (size_t)row0 * p.ldc) = st0;
+                        if (INTERIOR || row0 + 8 < p.M) *reinterpret_cast<u32x4*>(colp + (size_t)(row0 + 8) * p.ldc) = st1;
+                    }
                 }
             };
             if (m0 + BM <= p.M) f16_epilogue(std::true_type{});
