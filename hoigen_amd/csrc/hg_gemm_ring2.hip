@@ -348,15 +348,25 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                 if ((xmode & 32) && r > 0 && tkn < 8) {   // timing experiment (with bit 4): a tile's read-modify-write trickles out
                     ++tkn;                                 // under the next tile's K loop: 2 row loads + 4 stores per K-tile
                     float* xo = reinterpret_cast<float*>(p.out);
-                    const size_t o0 = (size_t)(tk_m0 + wm * 32 + (lane & 15)) * p.ldc + tk_n0 + wn * 32 + 4 * (lane >> 4) + (tkn & 1) * 128;
                     f32x4 t0, t1;
+                    const f32x4 junk = {1.f, 2.f, 3.f, 4.f};
+                    if (xmode & 128) {      // whole-line variant: every instruction covers 4 rows x 256 B (fp32) / 8 rows x 128 B (fp16)
+                        const size_t l0 = (size_t)(tk_m0 + wm * 64 + (tkn - 1) * 8 + (lane >> 4)) * p.ldc + tk_n0 + wn * 64 + (lane & 15) * 4;
+                        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off"
+                                     : "=&v"(t0), "=&v"(t1) : "v"(xo + l0), "v"(xo + l0 + (size_t)4 * p.ldc) : "memory");
+                        *reinterpret_cast<f32x4*>(xo + l0) = junk;
+                        *reinterpret_cast<f32x4*>(xo + l0 + (size_t)4 * p.ldc) = junk;
+                        *reinterpret_cast<f32x4*>(xo + l0) = junk;
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(p.out2) + ((size_t)(tk_m0 + wm * 64 + (tkn - 1) * 8 + (lane >> 3)) * p.ldc + tk_n0 + wn * 64) * 2 + (lane & 7) * 16) = junk;
+                    } else {
+                    const size_t o0 = (size_t)(tk_m0 + wm * 32 + (lane & 15)) * p.ldc + tk_n0 + wn * 32 + 4 * (lane >> 4) + (tkn & 1) * 128;
                     asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:64"
                                  : "=&v"(t0), "=&v"(t1) : "v"(xo + o0 + (size_t)(tkn >> 1) * 16 * p.ldc) : "memory");
-                    const f32x4 junk = {1.f, 2.f, 3.f, 4.f};
                     *reinterpret_cast<f32x4*>(xo + o0 + (size_t)(64 + (tkn >> 1) * 16) * p.ldc) = junk;
                     *reinterpret_cast<f32x4*>(xo + o0 + (size_t)(64 + (tkn >> 1) * 16) * p.ldc + 16) = junk;
                     *reinterpret_cast<f32x4*>(xo + o0 + (size_t)(64 + (tkn >> 1) * 16) * p.ldc + 32) = junk;
                     *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(p.out2) + ((size_t)(tk_m0 + wm * 32 + (lane & 15) + (tkn >> 1) * 16) * p.ldc + tk_n0 + wn * 32) * 2 + (lane >> 4) * 16) = junk;
+                    }
                     tkeep0 = t0; tkeep1 = t1;
                 }
             }
