@@ -279,6 +279,7 @@ def aggregate(recs, steps):
 # ----------------------------------------------------------------------------------------------------------------
 def run(args):
     import torch
+    torch.set_grad_enabled(False)      # inference only (the façade refuses gradient callers)
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -288,7 +289,10 @@ def run(args):
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # HG_BENCH_FORCE_COMM=1 (tests): one rank, but the RCCL process group, the side-stream event chain and the in-place
+    # all-gather run exactly as with N ranks - the only way to execute that leg on a 1-GPU box
+    force_comm = world == 1 and os.environ.get("HG_BENCH_FORCE_COMM", "0") == "1" and "RANK" in os.environ
+    if world > 1 or force_comm:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)   # RCCL
 
@@ -299,7 +303,8 @@ def run(args):
     model = build_model(synth.to_torch(synth.clip_state_dict(synth.VIT_B16, 0))).to(dev)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     crops = torch.randn(args.batch, 3, 224, 224, device=dev, generator=gen)     # resident in HBM
-    sharded = ShardedEncoder(model.visual.encode_into, args.batch, 512, dev) if world > 1 else None
+    sharded = (ShardedEncoder(model.visual.encode_into, args.batch, 512, dev, force_comm=force_comm)
+               if (world > 1 or force_comm) else None)
 
     def step():
         if sharded is not None:
@@ -310,7 +315,7 @@ def run(args):
         if sharded is not None:
             sharded.finish()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if world > 1 or force_comm:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -369,7 +374,7 @@ def run(args):
         rel = float(((out2.float() - out.float()).norm() / out.float().norm()).item())
 
     t = torch.tensor([dt, dt2], device=dev, dtype=torch.float64)
-    if world > 1:
+    if world > 1 or force_comm:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt, dt2 = float(t[0].item()), float(t[1].item())
 
@@ -402,7 +407,7 @@ def run(args):
                        "last_block": "all rows (HG_LAST_BLOCK_ROW0=0)",
                        "flops_per_crop_executed": round(FLOPS_PER_CROP / 1e9, 3),
                        "batch_per_gpu": args.batch, "global_batch": world * args.batch,
-                       "parallelism": f"dp{world}" + (f" + in-place all_gather[{world}x{args.batch}x512 f32] per step on a side stream" if world > 1 else "")},
+                       "parallelism": f"dp{world}" + (f" + in-place all_gather[{world}x{args.batch}x512 f32] per step on a side stream" if (world > 1 or force_comm) else "")},
             "step_ms": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "how": "hipEvents on the compute stream around every timed step"},
             "roofline": {"bound": "mfma",
                          "kernel": f"{KIND_NAMES.get(dom_kind, dom_kind)}: the kernel with the largest share of the step "
@@ -436,7 +441,7 @@ def run(args):
                 line["config3"] = config3(model, dev, with_cpu)
                 line["config4"] = config4(dev, with_cpu)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_comm:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -121,6 +121,7 @@ SIGNATURES = {
     "hg_preprocess_crops": (_I, [_P, _P, _I, _I, _P, _I, _I, _I, C.c_uint32, _P, _P, _P]),
     "hg_workspace_bytes": (_I, [_P, C.POINTER(C.c_uint64)]),
     "hg_test_gemm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "hg_test_gemm_ln": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hg_test_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "hg_profile_begin": (_I, [_P, _I, _I]),
     "hg_profile_end": (_I, [_P, _P, _I, C.POINTER(C.c_int32)]),

@@ -285,7 +285,8 @@ __device__ __forceinline__ int key_slot(int key) {
 }
 
 template <bool SELF>
-__global__ __launch_bounds__(256) void adapter_decoder_mfma(const float* __restrict__ down, int ld_down, DecW16 W,
+// `down` is not __restrict__: a chained layer (adapter_num_layers > 1) writes chain32 == down in place
+__global__ __launch_bounds__(256) void adapter_decoder_mfma(const float* down, int ld_down, DecW16 W,
                                                             const float* __restrict__ priors, const uint8_t* __restrict__ mask,
                                                             int L, int N, half_t* __restrict__ out16, float* chain32) {
     extern __shared__ __attribute__((aligned(16))) char smem_ad[];

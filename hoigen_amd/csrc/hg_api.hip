@@ -114,6 +114,9 @@ struct hg_ctx {
     int max_chunk_img = 256;
     int max_chunk_txt = 640;
     int max_chunk_rows = 32768;
+    // sticky device->host flag (host-mapped): set by clamp_eot when a caller-supplied text truncation was shorter than
+    // max(EOT)+1 (a stale host memo); reported as HG_ERR_INVALID by the next text call
+    int32_t* eot_flag = nullptr;
     // live per-kernel timing for bench.py (hg_profile_begin/end): hipEvent pairs around the launches of one kernel
     // kind (or of every GEMM and attention launch), on the stream the kernel is launched on
     int prof_kind = HG_PROF_OFF;
@@ -682,6 +685,14 @@ int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const Ada
     // post-norm decoder layer(s) over the 64-wide bottleneck (adapter...:186-200); with adapter_num_layers > 1 the
     // prior path chains mhsa_layers.0 .. N-1, the intermediate activations staying fp32 in place
     const int n_chain = ac.priors ? 1 + (int)a.extra.size() : 1;
+    // chained layers exist only in the MFMA decoder (one workgroup per sequence, <= 32 prior tokens): say so up front
+    // instead of failing inside the launch
+    if (n_chain > 1) {
+        const char* e = getenv("HG_ADAPTER_MFMA");
+        if ((e && e[0] == '0') || ac.N > 32)
+            return fail(c, HG_ERR_INVALID, "adapter_num_layers > 1 needs the MFMA decoder path: at most 32 prior tokens (got %d) "
+                                           "and HG_ADAPTER_MFMA != 0", ac.N);
+    }
     for (int z = 0; z < n_chain; ++z) {
         if (z > 0)
             for (int j = 0; j < 12; ++j) ad.dl[0][j] = a.extra[z - 1].dl[j];
@@ -725,6 +736,11 @@ hg_ctx* hg_create(int device) {
     if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
     hg_ctx* c = new hg_ctx();
     c->device = device;
+    {
+        DevGuard g(c);
+        if (hipHostMalloc((void**)&c->eot_flag, 64, hipHostMallocMapped) == hipSuccess && c->eot_flag) *c->eot_flag = 0;
+        else c->eot_flag = nullptr;
+    }
     if (const char* e = getenv("HG_CHUNK_ROWS")) {          // tuning knob: rows per VAE / mlp_net / cache-logits chunk
         const int v = atoi(e);
         if (v >= 256) c->max_chunk_rows = v;
@@ -747,6 +763,7 @@ void hg_destroy(hg_ctx* c) {
     for (Buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
+    if (c->eot_flag) (void)hipHostFree(c->eot_flag);
     delete c;
 }
 
@@ -859,6 +876,57 @@ int hg_test_gemm(hg_ctx* c, const float* a, const float* w, const float* bias, f
     ps.finish();
     if (e != hipSuccess) return fail(c, HG_ERR_HIP, "test gemm launch failed: %s", hipGetErrorString(e));
     if (f16out) HG_HIP(launch_f16_to_f32((const half_t*)c->qkv.p, out, (size_t)M * N, s));
+    return HG_OK;
+}
+
+int hg_test_gemm_ln(hg_ctx* c, const float* a, const float* w, const float* bias, float* out, int M, int N, int K, int epi,
+                    int kernel, const float* cs, const float* mr, const float* mu, const float* scale, float* out2,
+                    float* mr_out, float* mu_out, void* stream) {
+    if (!c || !a || !w || !out || M <= 0) return HG_ERR_INVALID;
+    const bool lnc = (epi == EPI_LN_BIAS_F16 || epi == EPI_LN_BIAS_QGELU_F16);
+    const bool rln = (epi == EPI_RESID_LN_F32 || epi == EPI_SCALE_RESID_LN_F32);
+    if (!lnc && !rln) return fail(c, HG_ERR_INVALID, "hg_test_gemm_ln: epi must be 8, 9, 10 or 12");
+    if (lnc && (!cs || !mr)) return fail(c, HG_ERR_INVALID, "hg_test_gemm_ln: epi 8/9 need cs and mr");
+    if (rln && (!mu || !out2 || !mr_out || !mu_out || (epi == EPI_SCALE_RESID_LN_F32 && !scale)))
+        return fail(c, HG_ERR_INVALID, "hg_test_gemm_ln: epi 10/12 need mu, out2, mr_out, mu_out (12: scale)");
+    if (N % 256) return fail(c, HG_ERR_INVALID, "hg_test_gemm_ln: N must be a multiple of 256");
+    hipStream_t s = (hipStream_t)stream;
+    HG_ON_DEVICE(c);
+    const size_t Mp = rup(M, 256);
+    const int sld = 4 * (N / 256);
+    int rc = ensure(c, c->h, Mp * K * 2);
+    if (!rc) rc = ensure(c, c->att, (size_t)N * K * 2);
+    if (!rc) rc = ensure(c, c->qkv, Mp * N * 2);
+    if (!rc) rc = ensure(c, c->mr, Mp * 2 * 4);
+    if (!rc) rc = ensure(c, c->mu, Mp * 4);
+    if (!rc) rc = ensure(c, c->stats, Mp * (size_t)sld * 2 * 4);
+    if (rc) return rc;
+    HG_HIP(launch_f32_to_f16(a, (half_t*)c->h.p, (size_t)M * K, s));
+    HG_HIP(launch_f32_to_f16(w, (half_t*)c->att.p, (size_t)N * K, s));
+    GemmArgs g{};
+    g.A = (half_t*)c->h.p; g.lda = K; g.W = (half_t*)c->att.p; g.bias = bias; g.M = M; g.N = N; g.K = K; g.ldc = N;
+    if (lnc) {
+        HG_HIP(hipMemsetAsync(c->mr.p, 0, Mp * 2 * 4, s));                  // padded rows are read by the tile's DMA
+        HG_HIP(hipMemcpyAsync(c->mr.p, mr, (size_t)M * 2 * 4, hipMemcpyDeviceToDevice, s));
+        g.cs = cs; g.mr = (const float*)c->mr.p; g.out = c->qkv.p;
+    } else {
+        HG_HIP(hipMemcpyAsync(c->mu.p, mu, (size_t)M * 4, hipMemcpyDeviceToDevice, s));
+        g.out = out; g.out2 = (half_t*)c->qkv.p; g.stats = (float*)c->stats.p; g.stats_ld = sld; g.mu = (const float*)c->mu.p;
+        g.pos = scale;
+    }
+    hipError_t e;
+    if (kernel == 2) e = gemm_ln_ok(epi, g) ? launch_gemm_ring(epi, g, s) : hipErrorInvalidValue;
+    else if (kernel == 3) e = gemm_duo_ok(epi, g) ? launch_gemm_duo(epi, g, s) : hipErrorInvalidValue;
+    else e = launch_gemm(epi, g, s);
+    if (e != hipSuccess) return fail(c, HG_ERR_HIP, "test gemm (ln) launch failed: %s", hipGetErrorString(e));
+    if (lnc) {
+        HG_HIP(launch_f16_to_f32((const half_t*)c->qkv.p, out, (size_t)M * N, s));
+    } else {
+        HG_HIP(launch_f16_to_f32((const half_t*)c->qkv.p, out2, (size_t)M * N, s));
+        HG_HIP(launch_finalize_stats((const float*)c->stats.p, (float*)c->mr.p, (float*)c->mu.p, M, sld, 64, s));
+        HG_HIP(hipMemcpyAsync(mr_out, c->mr.p, (size_t)M * 2 * 4, hipMemcpyDeviceToDevice, s));
+        HG_HIP(hipMemcpyAsync(mu_out, c->mu.p, (size_t)M * 4, hipMemcpyDeviceToDevice, s));
+    }
     return HG_OK;
 }
 
@@ -1292,6 +1360,18 @@ int hg_encode_image_prior(hg_ctx* c, const float* x_nchw, const float* priors, c
 }
 
 // ---- text tower -------------------------------------------------------------------------------------------
+// A truncation length that does not cover every EOT position (a stale host-side max(EOT)) must not gather
+// another sequence's row or read out of bounds: EOT indices are clamped into [0, Leff) on the device and a sticky
+// host-mapped flag makes the NEXT text call fail with HG_ERR_INVALID (this call cannot know without a sync).
+static int text_check_flag(hg_ctx* c) {
+    if (c->eot_flag && *(volatile int32_t*)c->eot_flag) {
+        *(volatile int32_t*)c->eot_flag = 0;
+        return fail(c, HG_ERR_INVALID, "a previous encode_text call was given trunc < max(EOT)+1: its EOT rows were clamped and "
+                                       "its outputs are invalid (recompute the truncation length from the current token ids)");
+    }
+    return HG_OK;
+}
+
 static int text_tail(hg_ctx* c, int Tc, int Leff, const int32_t* eot, float* out, hipStream_t s) {
     Text& t = c->text;
     const int D = t.D, E = t.E;
@@ -1319,6 +1399,7 @@ int hg_encode_text_ids(hg_ctx* c, const int32_t* ids, int T, int L, float* out, 
     if (T < 0 || !ids || !out || L < 1 || L > t.ctx) return fail(c, HG_ERR_INVALID, "bad arguments to encode_text_ids");
     hipStream_t s = (hipStream_t)stream;
     HG_ON_DEVICE(c);
+    if (int frc = text_check_flag(c)) return frc;
     const int Leff = (trunc > 0 && trunc < L) ? trunc : L;
     for (int t0 = 0; t0 < T; t0 += c->max_chunk_txt) {
         const int Tc = (T - t0 < c->max_chunk_txt) ? T - t0 : c->max_chunk_txt;
@@ -1329,6 +1410,7 @@ int hg_encode_text_ids(hg_ctx* c, const int32_t* ids, int T, int L, float* out, 
         int32_t* eot = (int32_t*)c->i32.p;
         // EOT position = argmax over the FULL row (clipnet/model.py:350); must lie inside Leff
         HG_HIP(launch_eot_argmax(ids + (size_t)t0 * L, Tc, L, eot, nullptr, s));
+        if (Leff < L) HG_HIP(launch_clamp_eot(eot, Tc, Leff, eot, c->eot_flag, s));
         HG_HIP(launch_embed_tokens(ids + (size_t)t0 * L, L, t.tok, t.pos, (float*)c->x.p, Tc, Leff, t.D, t.vocab, s));
         rc = text_tail(c, Tc, Leff, eot, out + (size_t)t0 * t.E, s);
         if (rc) return rc;
@@ -1346,6 +1428,7 @@ int hg_encode_text_embeds(hg_ctx* c, const float* prompts, const int32_t* eot_id
         return fail(c, HG_ERR_INVALID, "bad arguments to encode_text_embeds");
     hipStream_t s = (hipStream_t)stream;
     HG_ON_DEVICE(c);
+    if (int frc = text_check_flag(c)) return frc;
     const int Leff = (trunc > 0 && trunc < L) ? trunc : L;
     for (int r0 = 0; r0 < R; r0 += c->max_chunk_txt) {
         const int Rc = (R - r0 < c->max_chunk_txt) ? R - r0 : c->max_chunk_txt;
@@ -1353,7 +1436,14 @@ int hg_encode_text_embeds(hg_ctx* c, const float* prompts, const int32_t* eot_id
         if (!rc) rc = ensure(c, c->head16, rup(Rc, 256) * t.D * 2);
         if (rc) return rc;
         HG_HIP(launch_add_pos(prompts + (size_t)r0 * L * t.D, L, t.pos, (float*)c->x.p, Rc, Leff, t.D, s));
-        rc = text_tail(c, Rc, Leff, eot_idx + r0, out + (size_t)r0 * t.E, s);
+        const int32_t* eot = eot_idx + r0;
+        if (Leff < L) {
+            rc = ensure(c, c->i32, (size_t)(Rc + 4) * 4);
+            if (rc) return rc;
+            HG_HIP(launch_clamp_eot(eot, Rc, Leff, (int32_t*)c->i32.p, c->eot_flag, s));
+            eot = (const int32_t*)c->i32.p;
+        }
+        rc = text_tail(c, Rc, Leff, eot, out + (size_t)r0 * t.E, s);
         if (rc) return rc;
     }
     return HG_OK;

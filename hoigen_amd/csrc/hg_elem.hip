@@ -234,6 +234,22 @@ hipError_t launch_eot_argmax(const int32_t* ids, int T, int L, int32_t* eot, int
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void clamp_eot_kernel(const int32_t* in, int n, int Leff, int32_t* out, int32_t* flag) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int v = in[i];
+    if (v >= Leff) {
+        if (flag) *flag = 1;
+        v = Leff - 1;
+    }
+    out[i] = v < 0 ? 0 : v;
+}
+hipError_t launch_clamp_eot(const int32_t* in, int n, int Leff, int32_t* out, int32_t* flag, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(clamp_eot_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, n, Leff, out, flag);
+    return hipGetLastError();
+}
+
 // ---- dtype conversion / transposition (weight loading) ------------------------------------------------
 // dtype conversions, HBM-bound: 8 elements per lane (2 x 16-byte loads -> one 16-byte store, and back) when the
 // pointers are 16-byte aligned, scalar otherwise and for the tail

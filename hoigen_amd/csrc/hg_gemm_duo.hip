@@ -442,9 +442,13 @@ static hipError_t launch_duo_t(const GemmArgs& a, hipStream_t s) {
         gsz = (tiles_n + ngroups - 1) / ngroups;
     }
     // timing experiments: HG_DUO_LDS_CUT = bytes requested less (results wrong), HG_DUO_GRID = workgroups per CU
+#ifdef HG_EXPERIMENTS
     static const int xm_env = []() { const char* e = getenv("HG_DUO_XMODE"); return e ? atoi(e) : 0; }();
     static const int lds_cut = []() { const char* e = getenv("HG_DUO_LDS_CUT"); return e ? atoi(e) : 0; }();
-    static const int per_cu = []() { const char* e = getenv("HG_DUO_GRID"); return e ? atoi(e) : 2; }();
+    static const int per_cu = []() { const char* e = getenv("HG_DUO_GRID"); const int v = e ? atoi(e) : 2; return v >= 1 ? v : 2; }();
+#else
+    constexpr int xm_env = 0, lds_cut = 0, per_cu = 2;
+#endif
     const int grid2 = n_tiles < per_cu * n_cu ? n_tiles : per_cu * n_cu;
 #ifdef HG_STAMPS
     if (getenv("HG_STAMPS")) {

@@ -65,7 +65,7 @@ class ShardedEncoder:
     """
 
     def __init__(self, encode_into: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], b_local: int, embed_dim: int,
-                 device: torch.device, group=None, n_buffers: int = 2):
+                 device: torch.device, group=None, n_buffers: int = 2, force_comm: bool = False):
         self.encode_into, self.group = encode_into, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -73,21 +73,31 @@ class ShardedEncoder:
         self.cuda = device.type == "cuda"
         self.bufs = [torch.empty(self.world * b_local, embed_dim, dtype=torch.float32, device=device)
                      for _ in range(n_buffers)]
-        self.comm = torch.cuda.Stream(device) if (self.cuda and self.world > 1) else None
+        # force_comm: run the side-stream event chain and the in-place all-gather even with one rank (a 1-rank RCCL
+        # group executes the collective as a no-op copy) - the single-GPU test of the multi-GPU leg
+        self.force_comm = bool(force_comm and dist.is_initialized())
+        self.comm = torch.cuda.Stream(device) if (self.cuda and (self.world > 1 or self.force_comm)) else None
         self.done = [None] * n_buffers        # event: the gather into buffer i has completed
         self.i = 0
 
-    def step(self, images: torch.Tensor):
+    def step(self, images: torch.Tensor, consumed=None):
         """Encode this rank's batch and start the all-gather -> (gathered [W*B_local, E], done_event | None).
-        Wait for the event (or call ``finish``) before reading rows of other ranks."""
+        Wait for the event (or call ``finish``) before reading rows of other ranks.
+
+        Buffer reuse: ``n_buffers`` steps later the same buffer is overwritten, ordered only after ITS OWN gather (the
+        ``done`` event), on the stream that calls ``step``.  A consumer must therefore read the returned buffer on that
+        same stream (after ``wait_event(done_event)``), or finish reading before the ``n_buffers``-th next ``step``;
+        a consumer on another stream passes the event that marks its read complete as ``consumed``."""
         buf, i = self.bufs[self.i], self.i
         self.i = (self.i + 1) % len(self.bufs)
         lo = self.rank * self.b_local
         mine = buf[lo: lo + self.b_local]
         if self.comm is not None and self.done[i] is not None:
-            torch.cuda.current_stream().wait_event(self.done[i])    # the buffer's previous gather has been consumed
+            torch.cuda.current_stream().wait_event(self.done[i])    # the buffer's previous gather has completed
+        if self.cuda and consumed is not None:
+            torch.cuda.current_stream().wait_event(consumed)        # ... and its reader on another stream has finished
         self.encode_into(images, mine)
-        if self.world == 1:
+        if self.world == 1 and not self.force_comm:
             return buf, None
         if self.comm is None:                                       # CPU / gloo
             dist.all_gather_into_tensor(buf, mine.clone(), group=self.group)

@@ -16,6 +16,7 @@ only: outputs do not carry autograd history (SURVEY.md §8b "Ownership / errors 
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import math
 import random
 import weakref
@@ -37,6 +38,42 @@ def _require_cuda(t: torch.Tensor, what: str) -> None:
     if not t.is_cuda:
         raise RuntimeError(f"hoigen_amd: {what} must be on a HIP device (got {t.device}); the hot path has no "
                            "CPU implementation")
+
+
+def _tensors_in(obj):
+    if isinstance(obj, torch.Tensor):
+        yield obj
+    elif isinstance(obj, (tuple, list)):
+        for o in obj:
+            yield from _tensors_in(o)
+
+
+def _inference_only(fn):
+    """The HIP path records no autograd graph.  The reference back-propagates through two of these entry points
+    (VAE training through the frozen text tower, main_coop_vae.py:465-471; adapter / prompt fine-tuning,
+    main_tip_finetune.py:955-1031).  A caller that asks for gradients - grad mode on and either an input that
+    requires grad, or a module in ``train()`` mode that owns trainable parameters (where the reference would also apply
+    the adapters' dropout, CLIP_models_adapter_prior2.py:51-72) - gets an error instead of silently frozen
+    parameters.  ``eval()`` modules and ``torch.no_grad()`` callers (every inference call site of the reference) pass."""
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        if torch.is_grad_enabled():
+            what = None
+            if any(t.is_floating_point() and t.requires_grad for t in _tensors_in(list(args) + list(kwargs.values()))):
+                what = "an input that requires grad"
+            elif any(m.training and any(p.requires_grad for p in m.parameters())
+                     for m in ([self] if isinstance(self, nn.Module) else getattr(self, "_guard_modules", ()))):
+                what = "a module in train() mode with trainable parameters"
+            if what is not None:
+                raise RuntimeError(
+                    f"hoigen_amd: {type(self).__name__}.{fn.__name__} was called with {what} while grad mode is on. "
+                    "The HIP path is inference-only: it records no autograd graph and applies no train-mode dropout, so "
+                    "parameters would silently receive no gradients.  Call it under torch.no_grad() / in eval() mode, or "
+                    "use the reference's PyTorch modules for training (INTEGRATION.md, 'Training entry points').")
+        return fn(self, *args, **kwargs)
+
+    return wrapper
 
 
 class _Ctx:
@@ -288,6 +325,7 @@ class VisionTransformer(nn.Module):
         return h
 
     # -- forward ------------------------------------------------------------------------------
+    @_inference_only
     @torch.no_grad()
     def forward(self, x: torch.Tensor, prior=None):
         _require_cuda(x, "image batch")
@@ -323,6 +361,7 @@ class VisionTransformer(nn.Module):
                                                          local.data_ptr(), s), "hg_encode_image_prior")
         return glob.to(out_dtype), local.to(out_dtype)
 
+    @_inference_only
     @torch.no_grad()
     def encode_into(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
         """Variant A ``forward`` writing the fp32 embeddings into the caller's contiguous ``out [B,E]`` (e.g. this
@@ -402,7 +441,7 @@ class CLIP(nn.Module):
         self._text_sig = None
         #: run the causal text tower only up to max(EOT)+1 positions (identical selected outputs)
         self.truncate_text = True
-        self._trunc_memo = (None, 0, 0)
+        self._trunc_memo = (None, 0, 0, 0)
 
     def initialize_parameters(self):
         """clipnet/model.py:295-322."""
@@ -453,13 +492,22 @@ class CLIP(nn.Module):
         """max(EOT) + 1 over the call.  The grid depends on it, so the host has to read it: one tiny device->host
         copy, remembered for the token tensor it was computed from (the sampling loop passes the same
         ``tokenized_prompts`` every iteration, main_tip_finetune.py:759-824)."""
-        ref, ver, n = self._trunc_memo
-        if ref is not None and ref() is tokens and ver == tokens._version:      # the very same live tensor object
+        # Inference tensors (torch.inference_mode) track no version counter: no memo for them.  The memo is keyed on
+        # the live object, its version and its storage; a mutation that bumps none of them (torch.from_numpy shared
+        # memory, .data writes) cannot be seen here - the native side clamps EOT into the truncated length and
+        # reports HG_ERR_INVALID on the next call (hg_encode_text_ids), so a stale value never reads out of bounds.
+        try:
+            ver_now = tokens._version
+        except RuntimeError:
+            ver_now = None
+        ref, ver, ptr, n = self._trunc_memo
+        if (ver_now is not None and ref is not None and ref() is tokens and ver == ver_now
+                and ptr == tokens.data_ptr()):      # the very same live tensor object
             return n
         if eot is None:
             eot = tokens.argmax(dim=-1)
         n = int(eot.max().item()) + 1
-        self._trunc_memo = (weakref.ref(tokens), tokens._version, n)
+        self._trunc_memo = (weakref.ref(tokens), ver_now, tokens.data_ptr(), n) if ver_now is not None else (None, 0, 0, 0)
         return n
 
     # -- public API -----------------------------------------------------------------------------------
@@ -467,6 +515,7 @@ class CLIP(nn.Module):
         """clipnet/model.py:336-337 / CLIP_models_adapter_prior2.py:875-876."""
         return self.visual(image)
 
+    @_inference_only
     @torch.no_grad()
     def encode_text(self, text: torch.Tensor) -> torch.Tensor:
         """clipnet/model.py:339-352: text [T,L] integer ids (int64 or int32), EOT = largest id."""
@@ -485,6 +534,7 @@ class CLIP(nn.Module):
                                                       _stream_ptr(dev)), "hg_encode_text_ids")
         return out.to(self.dtype)
 
+    @_inference_only
     @torch.no_grad()
     def encode_text_embeds(self, prompts: torch.Tensor, tokenized_prompts: torch.Tensor) -> torch.Tensor:
         """TextEncoder.forward(prompts, tokenized_prompts) (main_coop_vae.py:54-63) -> fp32 [R,E]."""

@@ -17,7 +17,7 @@ from torch import nn
 
 from . import _lib
 from . import clip as _clip
-from .model import CLIP, Linear, _Ctx, _require_cuda, _sig, _stream_ptr
+from .model import CLIP, Linear, _Ctx, _inference_only, _require_cuda, _sig, _stream_ptr
 
 
 def weights_init(m):
@@ -64,6 +64,7 @@ class Encoder(nn.Module):
         w.enc_mean_w, w.enc_mean_b = t(self.mean.weight), t(self.mean.bias)
         w.enc_logvar_w, w.enc_logvar_b = t(self.log_var.weight), t(self.log_var.bias)
 
+    @_inference_only
     @torch.no_grad()
     def forward(self, x: torch.Tensor):
         _require_cuda(x, "Encoder input")
@@ -101,6 +102,7 @@ class Generator(nn.Module):
         w.gen_w0, w.gen_b0 = t(self.net[0].weight), t(self.net[0].bias)
         w.gen_w2, w.gen_b2 = t(self.net[2].weight), t(self.net[2].bias)
 
+    @_inference_only
     @torch.no_grad()
     def forward(self, z: torch.Tensor) -> torch.Tensor:
         _require_cuda(z, "Generator input")
@@ -127,9 +129,11 @@ class VAE:
 
     def __init__(self, netE: Encoder, netG: Generator):
         self.netE, self.netG = netE, netG
+        self._guard_modules = (netE, netG)
         self._ctx = _Ctx()
         self._sig = None
 
+    @_inference_only
     @torch.no_grad()
     def __call__(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None):
         _require_cuda(x, "VAE input")
@@ -161,6 +165,7 @@ class mlp_net(nn.Module):
         self._ctx = _Ctx()
         self._sig = None
 
+    @_inference_only
     @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         _require_cuda(x, "mlp_net input")
@@ -220,6 +225,7 @@ class TextEncoder(nn.Module):
         self.text_projection = clip_model.text_projection
         self.dtype = clip_model.dtype
 
+    @_inference_only
     def forward(self, prompts: torch.Tensor, tokenized_prompts: torch.Tensor) -> torch.Tensor:
         return self._clip.encode_text_embeds(prompts, tokenized_prompts)
 
@@ -266,6 +272,7 @@ class _PromptLearner(nn.Module):
         self._names_key = key
         self._f32_key = None              # fp32 operands of hg_assemble_prompts are rebuilt on the next forward
 
+    @_inference_only
     @torch.no_grad()
     def forward(self, bias: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         """main_coop_vae.py:119-128 -> prompts [R, L, D]."""

@@ -256,6 +256,16 @@ int hg_profile_end(hg_ctx*, hg_prof_rec* recs, int max_recs, int32_t* n_recs);
  * 3 bias+residual(f32), 4 bias->f32, 6 bias+ReLU->f32.  kernel: 0 auto, 1 simple 128x128, 2 persistent ring. */
 int hg_test_gemm(hg_ctx*, const float* a, const float* w, const float* bias, float* out, int M, int N, int K,
                  int epi, int kernel, void* stream);
+/* Test hook for the LayerNorm-folded / statistics-emitting epilogues the vision tower actually runs:
+ *   epi 8 / 9  (ring):  out = fp16( rstd[m] * (acc - mean[m] * cs[n]) + bias[n] ) [9: QuickGELU first], mr = [M][2] (mean, rstd)
+ *   epi 10     (ring2 / duo): x[M,N] (in `out`, read-modify-written) += acc + bias; out2 = fp16(x' - mu[m]);
+ *              per-row partial statistics -> finalize_stats -> mr_out [M][2] = (mean - mu[m], rstd), mu_out [M] = mean
+ *   epi 12     (duo, K >= 64): as 10 with the update scaled per column: x += (acc + bias) * scale[n]
+ * All pointers are device fp32; a / w are rounded to fp16 inside; out2 comes back as fp32.  kernel: 0 dispatcher, 2 ring
+ * family, 3 duo.  Unused pointers may be NULL. */
+int hg_test_gemm_ln(hg_ctx*, const float* a, const float* w, const float* bias, float* out, int M, int N, int K, int epi,
+                    int kernel, const float* cs, const float* mr, const float* mu, const float* scale, float* out2,
+                    float* mr_out, float* mu_out, void* stream);
 /* Test hook for the attention kernels (clipnet/model.py:171,181-183: the SDPA inside nn.MultiheadAttention, head_dim
  * 64): qkv [n_seq*L, 3*heads*64] fp32 on the device (rounded to fp16 inside).  q0 == NULL: full attention, out
  * [n_seq*L, heads*64].  q0 != NULL: [n_seq, heads*64] queries of ONE row per sequence (row sel[seq], device int32, or

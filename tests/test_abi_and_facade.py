@@ -101,6 +101,59 @@ def test_fails_loudly_without_gpu():
     assert _lib.lib().hg_create(0) is None
 
 
+def test_gradient_callers_fail_loudly():
+    """The two reference entry points that back-propagate through the path (VAE training through the frozen text tower,
+    main_coop_vae.py:465-471; adapter fine-tuning, main_tip_finetune.py:955-1031) must get an error, not silently
+    frozen parameters.  The check runs before any device work, so it is testable without a GPU."""
+    from hoigen_amd import vae
+    m = build_model(synth.to_torch(synth.clip_state_dict(synth.TINY, 10)))          # eval(), like the reference
+    with torch.enable_grad():
+        # (1) train() mode with trainable parameters: the fine-tuning engine calls upt.train()
+        m.train()
+        with pytest.raises(RuntimeError, match="inference-only"):
+            m.encode_image(torch.zeros(1, 3, 32, 32))
+        with pytest.raises(RuntimeError, match="inference-only"):
+            m.encode_text(torch.zeros(1, 16, dtype=torch.long))
+        m.eval()
+        # (2) an input that requires grad: TextEncoder(prompts) with prompts built from the learnable context
+        te = vae.TextEncoder(m).eval()
+        prompts = torch.zeros(2, 16, m.transformer.width, requires_grad=True)
+        with pytest.raises(RuntimeError, match="requires grad"):
+            te(prompts, torch.zeros(2, 16, dtype=torch.long))
+        E, G = vae.Encoder(), vae.Generator()                                        # netE.train() / netG.train()
+        with pytest.raises(RuntimeError, match="train\\(\\) mode"):
+            E(torch.zeros(2, 512))
+        with pytest.raises(RuntimeError, match="train\\(\\) mode"):
+            vae.VAE(E, G)(torch.zeros(2, 512), torch.zeros(2, 512))
+        with pytest.raises(RuntimeError, match="requires grad"):
+            G.eval()(torch.zeros(2, 512, requires_grad=True))
+        # eval() + frozen or not: plain inference passes the guard (and then fails for the missing device, here)
+        if not torch.cuda.is_available():
+            with pytest.raises(RuntimeError, match="HIP device"):
+                m.encode_image(torch.zeros(1, 3, 32, 32))
+    # under no_grad (every inference call site of the reference) train() mode is not an error either
+    m.train()
+    with torch.no_grad():
+        if not torch.cuda.is_available():
+            with pytest.raises(RuntimeError, match="HIP device"):
+                m.encode_image(torch.zeros(1, 3, 32, 32))
+
+
+def test_trunc_memo_tolerates_inference_tensors():
+    """Tensors made under torch.inference_mode() track no version counter: no memo, no crash."""
+    m = build_model(synth.to_torch(synth.clip_state_dict(synth.TINY, 10)))
+    with torch.inference_mode():
+        t = torch.zeros(3, 16, dtype=torch.long)
+        t[:, 5] = 7
+    assert m._trunc_len(t) == 6 and m._trunc_len(t) == 6
+    assert m._trunc_memo[0] is None
+    u = torch.zeros(3, 16, dtype=torch.long)
+    u[:, 9] = 7
+    assert m._trunc_len(u) == 10 and m._trunc_memo[0]() is u
+    u[:, 11] = 8                                    # version bump -> recomputed
+    assert m._trunc_len(u) == 12
+
+
 def test_ctx_before_lib_does_not_deadlock():
     """ctx() takes the module lock and then calls lib(): the lock must be re-entrant (regression)."""
     import subprocess, sys, os

@@ -64,3 +64,27 @@ def test_bench_line_schema_on_gpu():
     assert rf["kernel"].startswith(top)
     assert 0.8 * d["ms_per_step"] < sum(by_kernel.values()) < 1.05 * d["ms_per_step"]
     assert d["config4"]["ms"] > 0 and d["config3"]["truncated"]["ms"] < d["config3"]["full_77_tokens"]["ms"]
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_one_rank_runs_the_rccl_leg():
+    """`torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` with HG_BENCH_FORCE_COMM=1 runs
+    init_process_group("nccl", device_id=...), the barriers, the side-stream event chain and the in-place
+    all_gather_into_tensor of ShardedEncoder on the one GPU there is (launch model: main_tip_finetune.py:1205-1208,
+    328-332), so that the first real multi-GPU run does not die on plumbing."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update({"HG_BENCH_FORCE_COMM": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "MASTER_ADDR": "127.0.0.1"})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), BENCH, "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+           "--no-extra-configs", "--no-class-rows"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and "all_gather" in d["config"]["parallelism"] and d["value"] > 0

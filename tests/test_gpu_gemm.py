@@ -93,3 +93,130 @@ def test_ring_many_tiles_per_workgroup(ctx):
             assert torch.equal(g1, run(ctx, a, w, bias, epi, 3, out0)), "duo kernel"
     want = ref(a, w, bias, 4, None)
     assert (g1 - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+
+
+# ---- the epilogues the vision tower actually runs: LayerNorm folded into the consumer GEMM (8, 9), residual update that
+# ---- emits the centred fp16 copy and the row statistics (10), and the scaled variant behind the adapter (12)
+def run_ln(ctx, a, w, bias, epi, kernel, *, cs=None, mr=None, mu=None, scale=None, x0=None):
+    M, K = a.shape
+    N = w.shape[0]
+    p = lambda t: t.data_ptr() if t is not None else None
+    if epi in (8, 9):
+        out = torch.empty(M, N, device="cuda")
+        rc = _lib.lib().hg_test_gemm_ln(ctx, p(a), p(w), p(bias), p(out), M, N, K, epi, kernel, p(cs), p(mr), None, None,
+                                        None, None, None, None)
+        assert rc == 0, _lib.lib().hg_last_error(ctx)
+        torch.cuda.synchronize()
+        return out
+    out = x0.clone()
+    out2 = torch.empty(M, N, device="cuda")
+    mr_out = torch.empty(M, 2, device="cuda")
+    mu_out = torch.empty(M, device="cuda")
+    rc = _lib.lib().hg_test_gemm_ln(ctx, p(a), p(w), p(bias), p(out), M, N, K, epi, kernel, None, None, p(mu), p(scale),
+                                    p(out2), p(mr_out), p(mu_out), None)
+    assert rc == 0, _lib.lib().hg_last_error(ctx)
+    torch.cuda.synchronize()
+    return out, out2, mr_out, mu_out
+
+
+def _operands(M, N, K, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    a = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) * K ** -0.5
+    bias = torch.randn(N, device="cuda", generator=g) * 0.1
+    return g, a, w, bias
+
+
+# ragged M, K-tile counts 4 / 5 / 6 / 12 / 48; (8192, 2048, .) fills exactly one round of 256x256 tiles (two-phase loop),
+# the others run the 128-row variants
+LN_SHAPES = [(197 * 12 + 5, 768, 768), (256 * 33 + 100, 768, 256), (2048 + 37, 768, 320), (1024 + 3, 2304, 384),
+             (4096 + 77, 768, 3072), (8192, 2048, 256), (8192 - 60, 2048, 768)]
+
+
+@pytest.mark.parametrize("M,N,K", LN_SHAPES)
+@pytest.mark.parametrize("epi", [8, 9])
+def test_layernorm_folded_epilogues(ctx, M, N, K, epi):
+    """rstd * (x16 W'^T - mean * cs) + b'  against the same expression in fp32 PyTorch."""
+    g, a, w, bias = _operands(M, N, K, M + 3 * N + K + epi)
+    mean = torch.randn(M, device="cuda", generator=g) * 0.3
+    rstd = torch.rand(M, device="cuda", generator=g) * 1.5 + 0.5
+    mr = torch.stack([mean, rstd], 1).contiguous()
+    cs = w.half().float().sum(1)
+    acc = a.half().float() @ w.half().float().t()
+    want = rstd[:, None] * (acc - mean[:, None] * cs[None]) + bias
+    if epi == 9:
+        want = want * torch.sigmoid(1.702 * want)
+    want = want.half().float()
+    tol = 3e-3 * want.abs().max().item()
+    first = None
+    for it in range(3):                                        # repeated launches: a race shows as a flaky mismatch
+        got = run_ln(ctx, a, w, bias, epi, 0, cs=cs, mr=mr)
+        assert torch.isfinite(got).all()
+        assert (got - want).abs().max().item() <= tol, f"launch {it}"
+        first = got if first is None else first
+        assert torch.equal(got, first), "same inputs, different bits"
+
+
+@pytest.mark.parametrize("M,N,K", LN_SHAPES[:5])
+def test_residual_epilogue_emits_copy_and_statistics(ctx, M, N, K):
+    """EPI_RESID_LN_F32: x += acc + b; x16 = fp16(x - mu); (sum, M2) groups -> finalize_stats -> (mean - mu, rstd), mu = mean.
+    ring2 (128x256, the product path) and the duo kernel must agree bit for bit."""
+    g, a, w, bias = _operands(M, N, K, 5 * M + N + K)
+    x0 = torch.randn(M, N, device="cuda", generator=g) * 2 + torch.randn(M, 1, device="cuda", generator=g)   # rows with offsets
+    mu = x0.mean(1) + 0.05 * torch.randn(M, device="cuda", generator=g)      # "previous mean": close to, not equal to, the new one
+    xr = x0 + a.half().float() @ w.half().float().t() + bias
+    mean = xr.mean(1)
+    rstd = 1.0 / torch.sqrt(xr.var(1, unbiased=False) + 1e-5)
+    want16 = (xr - mu[:, None]).half().float()
+    scale = xr.abs().max().item()
+    ref_bits = None
+    for kernel in (2, 3):
+        for it in range(3):
+            x, x16, mr_out, mu_out = run_ln(ctx, a, w, bias, 10, kernel, mu=mu, x0=x0)
+            assert (x - xr).abs().max().item() <= 2e-5 * scale, (kernel, it)
+            assert (x16 - want16).abs().max().item() <= 2e-3 * (xr - mu[:, None]).abs().max().item(), (kernel, it)
+            assert (mu_out - mean).abs().max().item() <= 1e-5 * scale
+            assert ((mr_out[:, 0] - (mean - mu)).abs().max().item()) <= 1e-5 * scale
+            assert ((mr_out[:, 1] - rstd).abs() / rstd).max().item() <= 1e-4
+            bits = (x, x16, mr_out, mu_out)
+            if ref_bits is None:
+                ref_bits = bits
+            for u, v in zip(bits, ref_bits):
+                assert torch.equal(u, v), f"kernel {kernel} launch {it}: bits differ from ring2's first launch"
+
+
+@pytest.mark.parametrize("M,N,K", [(197 * 12 + 5, 768, 64), (256 * 33 + 100, 768, 64), (2048 + 37, 768, 128), (1024 + 3, 768, 192),
+                                   (4096 + 77, 768, 256)])
+def test_scaled_residual_epilogue_duo(ctx, M, N, K):
+    """EPI_SCALE_RESID_LN_F32 (adapter up_proj, K = 64 in production: one K-tile per tile, the path that skips the
+    vmcnt wait after a residual epilogue on every tile after the first)."""
+    g, a, w, bias = _operands(M, N, K, 7 * M + N + K)
+    x0 = torch.randn(M, N, device="cuda", generator=g)
+    sc = torch.randn(N, device="cuda", generator=g) * 0.5
+    mu = x0.mean(1)
+    xr = x0 + (a.half().float() @ w.half().float().t() + bias) * sc
+    mean = xr.mean(1)
+    rstd = 1.0 / torch.sqrt(xr.var(1, unbiased=False) + 1e-5)
+    scale = xr.abs().max().item()
+    first = None
+    for it in range(3):
+        x, x16, mr_out, mu_out = run_ln(ctx, a, w, bias, 12, 0, mu=mu, scale=sc, x0=x0)
+        assert (x - xr).abs().max().item() <= 2e-5 * scale
+        assert (x16 - (xr - mu[:, None]).half().float()).abs().max().item() <= 2e-3 * (xr - mu[:, None]).abs().max().item()
+        assert (mu_out - mean).abs().max().item() <= 1e-5 * scale
+        assert ((mr_out[:, 1] - rstd).abs() / rstd).max().item() <= 1e-4
+        first = (x, x16, mr_out) if first is None else first
+        assert all(torch.equal(u, v) for u, v in zip((x, x16, mr_out), first))
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 768, 64), (777, 512, 128), (2048 + 9, 256, 192)])
+@pytest.mark.parametrize("epi", [0, 3, 4])
+def test_duo_short_k(ctx, M, N, K, epi):
+    """The duo kernel admits K >= 64: K-tile counts 1, 2, 3 against the simple kernel, bit for bit."""
+    g, a, w, bias = _operands(M, N, K, M + N + K + epi)
+    out0 = torch.randn(M, N, device="cuda", generator=g) if epi == 3 else None
+    want = ref(a, w, bias, epi, out0)
+    got1 = run(ctx, a, w, bias, epi, 1, out0)
+    assert (got1 - want).abs().max().item() <= (3e-3 if epi == 0 else 2e-5) * want.abs().max().item()
+    for _ in range(3):
+        assert torch.equal(got1, run(ctx, a, w, bias, epi, 3, out0))

@@ -452,6 +452,22 @@ def test_text_truncation_is_exact_selection(fullA, g0):
     assert worst <= 2e-4, "running the causal tower on max(EOT)+1 positions must not change the EOT outputs"
 
 
+def test_stale_truncation_is_clamped_and_reported(fullA, g0, monkeypatch):
+    """a truncation length below max(EOT)+1 (a stale host memo) must neither read out of bounds nor stay
+    silent: EOT rows are clamped on the device, the NEXT text call raises, the one after works again."""
+    toks = ids_from_g0(g0, "hoi600", 16).to(dev())
+    good = fullA.encode_text(toks).float().cpu()
+    true_len = int(toks.argmax(-1).max()) + 1
+    monkeypatch.setattr(fullA, "_trunc_len", lambda *a, **k: true_len - 2)
+    bad = fullA.encode_text(toks).float().cpu()              # no crash; rows whose EOT was cut are wrong
+    assert torch.isfinite(bad).all()
+    monkeypatch.undo()
+    with pytest.raises(RuntimeError, match="trunc"):
+        fullA.encode_text(toks)
+    again = fullA.encode_text(toks).float().cpu()
+    assert torch.equal(again, good)
+
+
 def test_generation_pipeline_vs_oracle(g0):
     """z -> Generator -> PromptLearner -> TextEncoder -> L2 -> mlp_net, two branches in one
     text-tower pass, against the CPU oracle chain on the same latents."""

@@ -204,3 +204,58 @@ def test_entry_points_leave_the_current_device_alone(fullA):
     with torch.cuda.device(1):
         fullA.encode_image(torch.randn(2, 3, 224, 224, device=dev()))
         assert torch.cuda.current_device() == 1
+
+
+_RCCL_CHILD = r"""
+import os, sys
+sys.path.insert(0, {repo!r})
+import torch, torch.distributed as dist
+torch.set_grad_enabled(False)
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)   # RCCL
+from hoigen_amd import synth
+from hoigen_amd.distributed import ShardedEncoder
+from hoigen_amd.model import build_model
+model = build_model(synth.to_torch(synth.clip_state_dict(synth.VIT_B16, 0))).to(dev)
+B = 8
+enc = ShardedEncoder(model.visual.encode_into, B, 512, dev, force_comm=True)
+assert enc.comm is not None and enc.world == 1
+gen = torch.Generator(device=dev).manual_seed(7)
+batches = [torch.randn(B, 3, 224, 224, device=dev, generator=gen) for _ in range(3)]
+side = torch.cuda.Stream(dev)
+outs = []
+for x in batches:                      # three steps: both buffers are reused once, through the done-event chain
+    buf, ev = enc.step(x)
+    assert ev is not None
+    with torch.cuda.stream(side):      # a consumer on another stream waits for the gather's event
+        side.wait_event(ev)
+        outs.append(buf.clone())
+enc.finish()
+torch.cuda.synchronize()
+for x, o in zip(batches, outs):
+    ref = model.visual(x)                      # model.dtype (fp16): the same fp32 embeddings, cast
+    assert torch.equal(o.to(ref.dtype), ref), "gathered buffer differs from encode_image"
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_ONE_RANK_OK")
+"""
+
+
+def test_sharded_encoder_rccl_leg_on_one_rank():
+    """the RCCL leg of ShardedEncoder (side stream, event chain, in-place all_gather_into_tensor on an
+    `nccl` group created with device_id) executed on the one GPU of this box, in a fresh child process that creates the
+    process group before anything else touches the GPU; the gathered rows equal encode_image's."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_CHILD.format(repo=repo, port=port)], capture_output=True, text=True,
+                       env=env, timeout=900)
+    assert r.returncode == 0 and "RCCL_ONE_RANK_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])

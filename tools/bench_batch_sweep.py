@@ -2,6 +2,7 @@
 """encode_image latency / throughput over batch sizes (library default path), one JSON line per batch size."""
 import json, os, sys, time
 import torch
+torch.set_grad_enabled(False)   # inference only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hoigen_amd import synth
 from hoigen_amd.model import build_model

@@ -9,6 +9,7 @@ import sys
 import time
 
 import torch
+torch.set_grad_enabled(False)   # inference only
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hoigen_amd import clip, synth, vae  # noqa: E402

@@ -10,6 +10,7 @@ import time
 
 import numpy as np
 import torch
+torch.set_grad_enabled(False)   # inference only
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hoigen_amd import preprocess  # noqa: E402

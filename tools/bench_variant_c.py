@@ -5,6 +5,7 @@ Prints one JSON line; run under `rocprofv3 --kernel-trace --stats` for the per-k
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+torch.set_grad_enabled(False)   # inference only
 from hoigen_amd import synth
 from hoigen_amd.model import build_model
 

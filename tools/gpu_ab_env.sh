@@ -4,7 +4,7 @@ mkdir -p gpurun_out
 for cfg in $CONFIGS; do
   name=${cfg%%:*}; envs=${cfg#*:}
   if [ "$envs" != "-" ]; then for kv in ${envs//,/ }; do export $kv; done; fi
-  python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-configs > gpurun_out/ab_$name.log 2>&1
+  python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-configs ${BENCH_FLAGS} > gpurun_out/ab_$name.log 2>&1
   python3 - "$name" gpurun_out/ab_$name.log <<'PY'
 import json,sys
 l=[x for x in open(sys.argv[2]) if x.startswith('{')]
