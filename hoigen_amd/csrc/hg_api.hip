@@ -80,6 +80,9 @@ struct Vae {
     int dim = 0, eh = 0, gh = 0;
     half_t *e_w0 = nullptr, *e_wml = nullptr, *g_w0 = nullptr, *g_w2 = nullptr;
     float *e_b0 = nullptr, *e_bml = nullptr, *g_b0 = nullptr, *g_b2 = nullptr;
+    // the same stacked mean | log_var operand with its rows interleaved in blocks of 128 (EPI_VAE_REPARAM_F32)
+    half_t* e_wml_i = nullptr;
+    float* e_bml_i = nullptr;
     std::vector<void*> owned;
 };
 
@@ -1114,6 +1117,19 @@ int hg_load_vae(hg_ctx* c, int slot, const hg_vae_weights* w) {
         }
         free_all(sc);
         if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
+        // interleaved copy: rows [256b, 256b+128) = mean rows [128b, 128b+128), rows [256b+128, 256b+256) = log_var rows
+        keep_first(rc, dev_alloc(c, v.owned, (size_t)2 * v.dim * v.eh * 2, &p));
+        if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
+        v.e_wml_i = (half_t*)p;
+        keep_first(rc, dev_alloc(c, v.owned, (size_t)2 * v.dim * 4, &p));
+        if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
+        v.e_bml_i = (float*)p;
+        for (int b = 0; b < v.dim / 128; ++b)
+            for (int h = 0; h < 2; ++h) {
+                (void)hipMemcpy(v.e_wml_i + ((size_t)256 * b + 128 * h) * v.eh, v.e_wml + ((size_t)h * v.dim + 128 * b) * v.eh,
+                                (size_t)128 * v.eh * 2, hipMemcpyDeviceToDevice);
+                (void)hipMemcpy(v.e_bml_i + 256 * b + 128 * h, v.e_bml + h * v.dim + 128 * b, 128 * 4, hipMemcpyDeviceToDevice);
+            }
         v.enc = true;
     }
     if (w->gen_w0.ptr) {
@@ -1503,10 +1519,21 @@ int hg_vae_forward(hg_ctx* c, int slot, const float* x, const float* eps, int R,
         HG_HIP(gemm(c, EPI_BIAS_RELU_F16, g, s));
         // mean | log_var as ONE N = 2*dim GEMM whose two column halves land directly in the caller's tensors
         g = GemmArgs{};
-        g.A = h1; g.lda = v.eh; g.W = v.e_wml; g.bias = v.e_bml; g.out = mean_o; g.out_hi = lv_o; g.n_split = dim; g.ldc = dim;
-        g.M = Rc; g.N = 2 * dim; g.K = v.eh;
-        HG_HIP(gemm(c, EPI_BIAS_F32, g, s));
-        HG_HIP(launch_reparam(mean_o, lv_o, eps + o, Rc, dim, z ? z + o : nullptr, z16, dim, s));
+        g.A = h1; g.lda = v.eh; g.out = mean_o; g.out_hi = lv_o; g.ldc = dim; g.M = Rc; g.N = 2 * dim; g.K = v.eh;
+        // HG_VAE_FUSE=1: reparameterise in the GEMM's epilogue (interleaved rows: a lane holds mean_j and log_var_j) when the
+        // ring kernels take the shape - one launch and 410 MB of HBM traffic less per 100 k rows, the same arithmetic bit
+        // for bit, but measured 0.5-2 % SLOWER (round 3: 1.65 vs 1.61 ms per 100 k rows): the epilogue's 56 partial-line
+        // stores per wave cost the GEMM what the HBM-speed reparam kernel costs on its own, and nothing hides them.
+        // Default: the plain stacked GEMM + the reparam kernel.
+        g.W = v.e_wml_i; g.bias = v.e_bml_i; g.pos = eps + o; g.out2 = z16; g.out3 = z ? z + o : nullptr;
+        static const bool fuse_on = []() { const char* e = getenv("HG_VAE_FUSE"); return e && e[0] == '1'; }();
+        if (fuse_on && gemm_ln_ok(EPI_VAE_REPARAM_F32, g)) {
+            HG_HIP(gemm(c, EPI_VAE_REPARAM_F32, g, s));
+        } else {
+            g.W = v.e_wml; g.bias = v.e_bml; g.pos = nullptr; g.out2 = nullptr; g.out3 = nullptr; g.n_split = dim;
+            HG_HIP(gemm(c, EPI_BIAS_F32, g, s));
+            HG_HIP(launch_reparam(mean_o, lv_o, eps + o, Rc, dim, z ? z + o : nullptr, z16, dim, s));
+        }
         if (bias) {
             rc = generator_rows(c, v, z16, Rc, bias + o, s);
             if (rc) return rc;

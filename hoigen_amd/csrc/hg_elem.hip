@@ -1,7 +1,7 @@
 // Row / elementwise kernels (HBM-bound): LayerNorm, im2col, token embedding gather, prompt assembly,
 // reparameterisation, L2 normalisation, layout permutations, dtype conversion.  One wave per row
 // where a row reduction is needed; 16-byte accesses per lane.
-#include "hg_kernels.h"
+#include "hg_gemm_dev.h"
 
 namespace hg {
 
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void reparam_kernel(const f32x4* __restrict__ 
         const f32x4 m = mean[i], lv = logvar[i], e = eps[i];
         f32x4 zz;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) zz[k] = expf(0.5f * lv[k]) * e[k] + m[k];
+        for (int k = 0; k < 4; ++k) zz[k] = reparam1(m[k], lv[k], e[k]);
         if (z) z[i] = zz;
         const size_t r = i / D4;
         const int d4 = (int)(i - r * D4);

@@ -226,7 +226,8 @@ hipError_t launch_gemm(int epi, const GemmArgs& a, hipStream_t s) {
     if (epi == EPI_MU_BIAS_RELU_F32) return launch_gemm_simple(epi, a, s);
     const bool use_duo = duo >= 3 || (duo == 2 && epi != EPI_RESID_LN_F32) || (duo == 1 && epi == EPI_BIAS_RESID_F32);
     if (!force_simple && use_duo && gemm_duo_ok(epi, a)) return launch_gemm_duo(epi, a, s);
-    const bool ln = (epi == EPI_LN_BIAS_F16 || epi == EPI_LN_BIAS_QGELU_F16 || epi == EPI_RESID_LN_F32);
+    const bool ln = (epi == EPI_LN_BIAS_F16 || epi == EPI_LN_BIAS_QGELU_F16 || epi == EPI_RESID_LN_F32 ||
+                     epi == EPI_VAE_REPARAM_F32);
     if (ln) return gemm_ln_ok(epi, a) ? launch_gemm_ring(epi, a, s) : hipErrorInvalidValue;   // ring kernels only
     if (!force_simple && gemm_ring_ok(a)) return launch_gemm_ring(epi, a, s);
     return launch_gemm_simple(epi, a, s);

@@ -45,6 +45,12 @@ __device__ __forceinline__ f32x4 quick_gelu4(f32x4 v, f32x4 kk) {
     return o;
 }
 
+// z = exp(0.5 * log_var) * eps + mean (main_coop_vae.py:445-447), one expression for the stand-alone kernel and the GEMM
+// epilogue (a row's z must not depend on which of the two its chunk size selects)
+__device__ __forceinline__ float reparam1(float mean, float log_var, float eps) {
+    return __builtin_fmaf(expf(0.5f * log_var), eps, mean);
+}
+
 template <int EPI>
 __device__ __forceinline__ void epilogue_ring(const GemmArgs& p, int m, int n, f32x4 v) {
     if (m >= p.M) return;

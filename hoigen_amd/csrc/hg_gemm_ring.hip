@@ -87,7 +87,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     // the next tile pass before its operands have landed)
     constexpr bool F16_STORES = (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_BIAS_RELU_F16 ||
                                  EPI == EPI_LN_BIAS_F16 || EPI == EPI_LN_BIAS_QGELU_F16);
-    constexpr int E_RAW = RLN ? 8 * MF + 4 * MF + 2 * MF : (F16_STORES ? 4 * MF : 8 * MF);
+    constexpr bool VRP = (EPI == EPI_VAE_REPARAM_F32);     // mean | log_var tile halves -> mean, log_var, z, z16
+    constexpr int E_RAW = RLN ? 8 * MF + 4 * MF + 2 * MF : (VRP ? 14 * MF : (F16_STORES ? 4 * MF : 8 * MF));
     constexpr int E = E_RAW > 52 ? 52 : E_RAW;
     // RESID at MF = 2: the residual rows are fetched one K-tile before the epilogue (64 spare VGPRs)
     constexpr bool XPRE = RESID && MF == 2;
@@ -676,6 +677,65 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             };
             if (m0 + BM <= p.M) f16_epilogue(std::true_type{});
             else f16_epilogue(std::false_type{});
+        } else if constexpr (VRP) {
+            // VAE encoder head: column block hb = 0 of the tile holds mean_j, hb = 1 log_var_j of the same j = tn*128 +
+            // wn*32 + g2*16 + 4q .. +3 (rows interleaved at load), so the reparameterisation runs on the accumulators.
+            // The fragment registers are dead here: all 4*MF eps chunks of the lane are fetched up front (one exposed HBM
+            // round trip per tile instead of one per row group).
+            const int q = lane >> 4;
+            const float* epsp = p.pos;
+            float* meanp = reinterpret_cast<float*>(p.out);
+            float* lvp = reinterpret_cast<float*>(p.out_hi);
+            const int jb = (n0 >> 1) + wn * 32 + 4 * q;
+            f32x4 ep[2 * MF][2];
+#pragma unroll
+            for (int rg = 0; rg < 2 * MF; ++rg) {
+                int m = m0 + (rg / MF) * (BM / 2) + wm * MF * 16 + (rg % MF) * 16 + (lane & 15);
+                m = m < p.M ? m : p.M - 1;
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2)
+                    ep[rg][g2] = *reinterpret_cast<const f32x4*>(epsp + (size_t)m * p.ldc + jb + g2 * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int rp = 0; rp < MF; ++rp) {               // pairs of 16-row blocks (f, f + 1): the fp16 copy leaves as 16-byte stores
+                const int ha = (2 * rp) / MF, f0 = (2 * rp) % MF;
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const int nl = n0 + wn * 32 + g2 * 16 + 4 * q;          // bias index of the mean column (+128: log_var)
+                    const f32x4 bm = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + nl * 4);
+                    const f32x4 bl = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (nl + 128) * 4);
+                    half4 zh[2];
+#pragma unroll
+                    for (int df = 0; df < 2; ++df) {
+                        const int f = f0 + df, rg = ha * MF + f;
+                        const int m = m0 + ha * (BM / 2) + wm * MF * 16 + f * 16 + (lane & 15);
+                        const f32x4 mean = acc[ha][0][f][g2] + bm, lv = acc[ha][1][f][g2] + bl;
+                        f32x4 z;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            z[e] = reparam1(mean[e], lv[e], ep[rg][g2][e]);
+                            zh[df][e] = (half_t)z[e];
+                        }
+                        if (m < p.M) {
+                            const size_t o = (size_t)m * p.ldc + jb + g2 * 16;
+                            *reinterpret_cast<f32x4*>(meanp + o) = mean;
+                            *reinterpret_cast<f32x4*>(lvp + o) = lv;
+                            if (p.out3) *reinterpret_cast<f32x4*>(p.out3 + o) = z;
+                        }
+                    }
+                    // even 16-lane groups end up with 8 consecutive columns of block f0's row, odd groups of block f0 + 1's
+                    const u32x2 ux = __builtin_bit_cast(u32x2, zh[0]), uy = __builtin_bit_cast(u32x2, zh[1]);
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(ux[0], uy[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(ux[1], uy[1], false, false);
+                    const u32x4 o16 = {s0[0], s1[0], s0[1], s1[1]};
+                    const int m16 = m0 + ha * (BM / 2) + wm * MF * 16 + f0 * 16 + (lane & 15) + ((q & 1) ? 16 : 0);
+                    if (m16 < p.M)
+                        *reinterpret_cast<u32x4*>(p.out2 + (size_t)m16 * p.ldc + (n0 >> 1) + wn * 32 + g2 * 16 + 4 * (q & ~1)) = o16;
+                }
+            }
         } else if constexpr (ROLL) {
             // residual epilogue through the rolling window: chunk c is consumed, stored, and its window slot is
             // refilled with chunk c + ROLL_W (the sched_barrier keeps the compiler from hoisting the refills)
@@ -917,12 +977,13 @@ bool gemm_ring_ok(const GemmArgs& a) {
 
 bool gemm_ln_ok(int epi, const GemmArgs& a) {
     if (!gemm_ring_ok(a)) return false;
+    if (epi == EPI_VAE_REPARAM_F32) return a.out && a.out_hi && a.out2 && a.pos && a.ldc * 2 == a.N;
     if (epi == EPI_RESID_LN_F32) return gemm_ring2_ok(a) && a.out2 && a.stats && a.mu && a.stats_ld == 4 * (a.N / 256);
     return a.cs && a.mr && a.N <= 3584;      // 128 KiB ring + 2 * N * 4 + 2 KiB of LDS; mr readable for padded rows
 }
 
 hipError_t launch_gemm_ring(int epi, const GemmArgs& a, hipStream_t s) {
-    const bool lnc = (epi == EPI_LN_BIAS_F16 || epi == EPI_LN_BIAS_QGELU_F16);
+    const bool lnc = (epi == EPI_LN_BIAS_F16 || epi == EPI_LN_BIAS_QGELU_F16 || epi == EPI_VAE_REPARAM_F32);   // this kernel only
     const bool resid = (epi == EPI_BIAS_RESID_F32 || epi == EPI_SCALE_RESID_F32 || epi == EPI_RESID_LN_F32);
     // 256x256 tiles when they fill the chip evenly enough, else 128x256 (N = 768 GEMMs: 591 vs 1182 tiles).
     // The 128x256 kernel needs 50 % more global->LDS traffic per FLOP and runs at ~0.8 of a 256x256 tile's time
@@ -958,6 +1019,7 @@ hipError_t launch_gemm_ring(int epi, const GemmArgs& a, hipStream_t s) {
         HG_RING(EPI_SCALE_RESID_F32);
         HG_RING(EPI_LN_BIAS_F16);
         HG_RING(EPI_LN_BIAS_QGELU_F16);
+        HG_RING(EPI_VAE_REPARAM_F32);
         case EPI_RESID_LN_F32: return launch_ring_t<4, EPI_RESID_LN_F32, false>(a, s);
         default: return hipErrorInvalidValue;
     }

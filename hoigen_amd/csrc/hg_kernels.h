@@ -30,7 +30,12 @@ enum Epilogue : int {
     EPI_MU_BIAS_RELU_F32 = 11,
     // EPI_RESID_LN_F32 with the update scaled per column: out fp32 += (acc + bias) * pos[n]; fp16 copy + statistics
     // (adapter up_proj: LayerNorm folding stays on behind the adapter; duo kernel only)
-    EPI_SCALE_RESID_LN_F32 = 12
+    EPI_SCALE_RESID_LN_F32 = 12,
+    // CoOp-VAE encoder head (main_coop_vae.py:276-279,445-447): W = the mean / log_var weights stacked with their rows
+    // interleaved in blocks of 128 (tile column block 0 = mean columns j, block 1 = log_var columns j), so one lane holds
+    // mean_j and log_var_j of a row:  mean = out[m][j], log_var = out_hi[m][j], z = exp(0.5 log_var) * eps + mean with
+    // eps = pos[m][j] -> out3 (fp32, nullable) and out2 (fp16, the generator's operand); ring kernels only
+    EPI_VAE_REPARAM_F32 = 13
 };
 
 struct GemmArgs {
@@ -52,6 +57,7 @@ struct GemmArgs {
     // (the stacked mean | log_var GEMM of the VAE encoder writes its two halves straight into the caller's tensors)
     void* out_hi = nullptr;
     int n_split = 0;                     // multiple of 16
+    float* out3 = nullptr;               // EPI_VAE_REPARAM_F32: z (fp32), leading dimension ldc; may be null
     unsigned long long* dbg = nullptr;   // diagnostics: s_memtime totals (HG_STAMPS build), normally null
 };
 

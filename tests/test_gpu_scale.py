@@ -259,3 +259,45 @@ def test_sharded_encoder_rccl_leg_on_one_rank():
     r = subprocess.run([sys.executable, "-c", _RCCL_CHILD.format(repo=repo, port=port)], capture_output=True, text=True,
                        env=env, timeout=900)
     assert r.returncode == 0 and "RCCL_ONE_RANK_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+_VAE_CHILD = r"""
+import sys
+sys.path.insert(0, {repo!r})
+import torch
+torch.set_grad_enabled(False)
+from hoigen_amd import synth, vae
+d = torch.device("cuda:0")
+E, G = vae.Encoder().to(d).eval(), vae.Generator().to(d).eval()
+E.load_state_dict(synth.to_torch(synth.encoder_state_dict(2)))
+G.load_state_dict(synth.to_torch(synth.generator_state_dict(3)))
+out = {{}}
+for R in (1000, 33000):
+    g = torch.Generator(device=d).manual_seed(R)
+    x = vae.l2_normalize(torch.randn(R, 512, device=d, generator=g))
+    eps = torch.randn(R, 512, device=d, generator=g)
+    out[R] = [t.cpu() for t in vae.VAE(E, G)(x, eps)]
+torch.save(out, {path!r})
+print("VAE_CHILD_OK")
+"""
+
+
+def test_vae_reparameterise_in_gemm_epilogue_equals_separate_kernel(tmp_path):
+    """HG_VAE_FUSE=1 (EPI_VAE_REPARAM_F32: reparameterisation on the accumulators of the row-interleaved mean | log_var GEMM,
+    main_coop_vae.py:276-279,445-447) must give the bits of the default path (stacked GEMM + reparam kernel): 1000 rows run
+    the 128-row ring variant, 33 000 rows the 256-row two-phase loop plus a 232-row remainder on the unfused path."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for fuse in ("1", "0"):
+        path = str(tmp_path / f"vae_{fuse}.pt")
+        env = dict(os.environ, HG_VAE_FUSE=fuse)
+        r = subprocess.run([sys.executable, "-c", _VAE_CHILD.format(repo=repo, path=path)], capture_output=True, text=True,
+                           env=env, timeout=900)
+        assert r.returncode == 0 and "VAE_CHILD_OK" in r.stdout, r.stderr[-2000:]
+        res[fuse] = torch.load(path)
+    for R in (1000, 33000):
+        for a, b, name in zip(res["1"][R], res["0"][R], ("mean", "log_var", "z", "bias")):
+            assert torch.isfinite(a).all()
+            assert torch.equal(a, b), f"R={R} {name}: fused and separate reparameterisation differ"
