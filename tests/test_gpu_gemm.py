@@ -157,7 +157,12 @@ def test_layernorm_folded_epilogues(ctx, M, N, K, epi):
         assert torch.equal(got, first), "same inputs, different bits"
 
 
-@pytest.mark.parametrize("M,N,K", LN_SHAPES[:5])
+# more residual shapes: K-tile counts 12, 13, 48 on full 128-row tiles; fewer tiles than CUs, several tiles per workgroup
+RESID_SHAPES = LN_SHAPES[:5] + [(128 * 40, 768, 768), (128 * 37, 768, 832), (128 * 41, 768, 3072), (128 * 300, 768, 768),
+                                (128 * 394, 768, 768), (128 * 24, 2304, 1024)]
+
+
+@pytest.mark.parametrize("M,N,K", RESID_SHAPES)
 def test_residual_epilogue_emits_copy_and_statistics(ctx, M, N, K):
     """EPI_RESID_LN_F32: x += acc + b; x16 = fp16(x - mu); (sum, M2) groups -> finalize_stats -> (mean - mu, rstd), mu = mean.
     ring2 (128x256, the product path) and the duo kernel must agree bit for bit on the stream and its copy."""
