@@ -884,9 +884,16 @@ static hipError_t launch_ring_t(const GemmArgs& a, hipStream_t s) {
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / 256;
     const int n_tiles = tiles_m * tiles_n;
     int grid = n_tiles < n_cu ? n_tiles : n_cu;
-#ifdef HG_EXPERIMENTS
-    if (const char* e = getenv("HG_RING_GRID")) grid = atoi(e) < grid ? atoi(e) : grid;   // fewer CUs: how does a tile's time change?
-#endif
+    // Even rounds: the tiles take `rounds` passes over the CUs whatever the grid, so use only as many workgroups as fill every
+    // round (a multiple of 8: the XCD-chunked tile order needs it).  c_fc at batch 256: 2364 tiles = 10 rounds on 240
+    // workgroups instead of 9.23 on 256 - the same number of rounds with fewer CUs contending for L2 / HBM: 236-239 -> 230 us
+    // (round 3, one box; QKV's 1773 tiles stay on 256).  HG_RING_GRID overrides.
+    if (MF == 4 && n_tiles > n_cu) {
+        const int rounds = (n_tiles + n_cu - 1) / n_cu;
+        const int g8 = (((n_tiles + rounds - 1) / rounds) + 7) & ~7;
+        if (g8 < grid) grid = g8;
+    }
+    if (const char* e = getenv("HG_RING_GRID")) { const int v = atoi(e); if (v >= 8 && v <= n_cu && v <= n_tiles) grid = v; }
     const size_t a_bytes = (size_t)tiles_m * BM * a.lda * 2;      // A is allocated with rows padded to 256
     static const int mode = []() {
         const char* e = getenv("HG_RING_MODE");
