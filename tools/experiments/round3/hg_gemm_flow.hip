@@ -115,16 +115,28 @@ __global__ __launch_bounds__(512, 2) void gemm_flow(const GemmArgs p, const int 
             tile_of(slot + ld.r * cpx, tm, tn);
             ld.sA = tm * BM * p.lda * 2;
             ld.sW = tn * 256 * p.K * 2;
+#ifdef FLOW_TILE0      // timing experiment: every tile streams tile 0 (operands from L2)
+            ld.sA = 0; ld.sW = 0;
+#endif
+#ifdef FLOW_A0         // timing experiment: the A panel of tile 0 only (A from L2, W as it is)
+            ld.sA = 0;
+#endif
         }
         ld.st = ld.st == (NST - 1) * STAGE ? 0 : ld.st + STAGE;
     };
     auto dma_A = [&](auto I) {
         constexpr int i = decltype(I)::value;
+#ifdef FLOW_NO_DMA
+        return;
+#endif
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (HG_LDS void*)(smem + ld.st + wave * 2 * 1024), 16, voffA[i],
                                                  ld.sA + ld.kt * (BK * 2), i * 1024, 0);
     };
     auto dma_W = [&](auto I) {
         constexpr int i = decltype(I)::value;
+#ifdef FLOW_NO_DMA
+        return;
+#endif
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (HG_LDS void*)(smem + ld.st + AB + wave * 4 * 1024), 16, voffW[i],
                                                  ld.sW + ld.kt * (BK * 2), i * 1024, 0);
     };
@@ -148,24 +160,38 @@ __global__ __launch_bounds__(512, 2) void gemm_flow(const GemmArgs p, const int 
     const int w_row = AB + (wn * 32 + (lane & 15)) * 128;            // + hb*WH + g2*2048
 
     half8 fa[2][2][2], fw[2][2][2];                                   // [k-step][ha][f], [k-step][hb][g2]
-    auto read_frags = [&](auto KS, int st) {
+    auto read_fa = [&](auto KS, int st) {
         constexpr int ks = decltype(KS)::value;
+#ifdef FLOW_NO_READ
+        return;
+#endif
 #pragma unroll
         for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
             for (int f = 0; f < 2; ++f)
                 fa[ks][ha][f] = *reinterpret_cast<const half8*>(smem + st + ha * 8192 + a_row + f * 2048 + coff[ks]);
+    };
+    auto read_fw = [&](auto KS, int st) {
+        constexpr int ks = decltype(KS)::value;
+#ifdef FLOW_NO_READ
+        return;
+#endif
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
             for (int g2 = 0; g2 < 2; ++g2)
                 fw[ks][hb][g2] = *reinterpret_cast<const half8*>(smem + st + hb * WH + w_row + g2 * 2048 + coff[ks]);
     };
+    auto read_frags = [&](auto KS, int st) { read_fa(KS, st); read_fw(KS, st); };
     f32x4 acc[2][2][2][2];
-    auto mma = [&](auto KS) {
-        constexpr int ks = decltype(KS)::value;
+    auto mma = [&](auto KS, auto HA) {
+        constexpr int ks = decltype(KS)::value, ha = decltype(HA)::value;
+#ifdef FLOW_NO_MFMA
 #pragma unroll
-        for (int ha = 0; ha < 2; ++ha)
+        for (int f = 0; f < 2; ++f) asm volatile("" ::"v"(fa[ks][ha][f]), "v"(fw[ks][f][0]), "v"(fw[ks][f][1]));
+        return;
+#endif
+        {
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
@@ -174,13 +200,14 @@ __global__ __launch_bounds__(512, 2) void gemm_flow(const GemmArgs p, const int 
                     for (int g2 = 0; g2 < 2; ++g2)
                         acc[ha][hb][f][g2] =
                             __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[ks][hb][g2], fa[ks][ha][f], acc[ha][hb][f][g2], 0, 0, 0);
+        }
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    // [16 MFMAs with the 8 fragment reads of the next step between them]: one read per two MFMAs
+    // [8 MFMAs with 4 fragment reads of the next step between them]: one read per two MFMAs
     auto interleave = [&]() {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 4; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -188,7 +215,9 @@ __global__ __launch_bounds__(512, 2) void gemm_flow(const GemmArgs p, const int 
     };
     auto end_step = [&]() {
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the next step's fragments are in registers, the stage is read
+#ifndef FLOW_NO_BARRIER
         barrier_raw();
+#endif
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -209,6 +238,7 @@ __global__ __launch_bounds__(512, 2) void gemm_flow(const GemmArgs p, const int 
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_sched_barrier(0);
 
+    const bool late = wave >= 4;
     int stg = 0;                               // LDS stage of the current K-tile
     bool prev_full = false;
     for (int r = 0; r < my_tiles; ++r) {
@@ -252,10 +282,22 @@ __global__ __launch_bounds__(512, 2) void gemm_flow(const GemmArgs p, const int 
             stg = stg == NST - 1 ? 0 : stg + 1;
             const int nst = stg * STAGE;       // stage of the next K-tile of the stream
             // ---------------- step (t, k0): second half of K-tile t+2 (the cursor was advanced by the previous step)
-            if (KIND < 3 || more) issue_second();
-            if constexpr (KIND == 3) load_xres(0);
-            mma(I0{});
-            read_frags(I1{}, st);
+            // DMA issue blocks the issuing wave while the CU's address unit works through the pieces: waves 0-3 (one per SIMD)
+            // issue in front of their MFMAs, waves 4-7 between their two halves - a SIMD always has a wave feeding the pipe
+            if (!late) {
+                if (KIND < 3 || more) issue_second();
+                if constexpr (KIND == 3) load_xres(0);
+            }
+            mma(I0{}, I0{});
+            read_fa(I1{}, st);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            if (late) {
+                if (KIND < 3 || more) issue_second();
+                if constexpr (KIND == 3) load_xres(0);
+            }
+            mma(I0{}, I1{});
+            read_fw(I1{}, st);
             interleave();
             __builtin_amdgcn_sched_barrier(0);
             // K-tile t+1 must have landed: all but the DMA instructions issued since its last piece
@@ -265,10 +307,20 @@ __global__ __launch_bounds__(512, 2) void gemm_flow(const GemmArgs p, const int 
             else { if (more) wait_vm<NY + RA + RB>(); }          // last K-tile: K-tile t+1 is the next tile's first
             end_step();
             // ---------------- step (t, k1): first half of K-tile t+3
-            if (KIND < 2 || more) issue_first(std::integral_constant<int, KIND == 2 ? 1 : 0>{});
-            if constexpr (KIND == 3) load_xres(1);
-            mma(I1{});
-            if (KIND < 4 || more) read_frags(I0{}, nst);
+            if (!late) {
+                if (KIND < 2 || more) issue_first(std::integral_constant<int, KIND == 2 ? 1 : 0>{});
+                if constexpr (KIND == 3) load_xres(1);
+            }
+            mma(I1{}, I0{});
+            if (KIND < 4 || more) read_fa(I0{}, nst);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            if (late) {
+                if (KIND < 2 || more) issue_first(std::integral_constant<int, KIND == 2 ? 1 : 0>{});
+                if constexpr (KIND == 3) load_xres(1);
+            }
+            mma(I1{}, I1{});
+            if (KIND < 4 || more) read_fw(I0{}, nst);
             interleave();
             __builtin_amdgcn_sched_barrier(0);
             end_step();
