@@ -1,0 +1,495 @@
+// Fused scaled-dot-product attention for gfx950, head_dim 64, whole K/V of one (sequence, head) LDS
+// resident (L <= 224: 197 ViT tokens, 77 text tokens).  Replaces the SDPA inside
+// nn.MultiheadAttention (clipnet/model.py:171,181-183).  The [L,L] score matrix
+// never leaves registers.
+//
+// One workgroup per (sequence, head) with ONE WAVE PER 32-QUERY TILE (7 waves for L = 197, 3 for
+// L = 77).  K and V rows (128 B each) are DMA'd global -> LDS (global_load_lds, XOR-swizzled on the
+// source address).  Each wave walks the key tiles with an online softmax:
+//   S^T = K_tile Q^T      v_mfma_f32_32x32x16_f16, keys on MFMA rows, queries on lanes -> a lane holds
+//                         one query's 16 scores of the tile: max / sum are register reductions plus
+//                         one cross-half exchange
+//   O^T += V_tile^T P^T   P^T (fp16) is directly the B operand; V^T fragments come from the hardware
+//                         transposing read ds_read_b64_tr_b16 in the k-order the accumulator layout
+//                         dictates
+// The running max only triggers a rescale of O when some query's max actually grew (wave-uniform
+// branch).  Softmax statistics and accumulation are fp32; masking (keys >= L, causal diagonal) is
+// applied only on the tiles that need it.
+#include <stdlib.h>
+
+#include "hg_kernels.h"
+
+namespace hg {
+
+static constexpr int HD = 64;            // head dim
+static constexpr int ROWB = HD * 2;      // bytes per K/V row in LDS
+static constexpr int TILEB = 32 * ROWB;  // bytes per 32-key tile
+
+__device__ __forceinline__ int swz_k(int row) { return (row >> 1) & 7; }          // b128 row reads
+__device__ __forceinline__ int swz_v(int row) { return ((row >> 1) & 1) << 2; }   // tr_b16 reads
+
+// One 32-key tile of the online softmax for this wave's 32 queries (lane = query qcol, key half hh), in two parts so
+// that a caller can reuse its Q registers in between: tile_scores() S^T = K_tile Q^T; tile_softmax_pv()
+// running max / rescale, P, O^T += V_tile^T P^T.  kb / vb: LDS bases of the tile's K and V rows.  Shared by the
+// whole-sequence kernel and its one-row variant, so the two are bit-identical (a streaming kernel over an LDS ring of
+// key tiles and a persistent variant were built on the same two functions and measured slower: DESIGN.md section 4).
+__device__ __forceinline__ void tile_scores(const char* kb, const int (&k_off)[4], const half8 (&qf)[4], f32x16& s) {
+    // ---- S^T tile: lane holds keys kt*32 + (r&3) + 8*(r>>2) + 4*hh of query q
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const half8 kf = *reinterpret_cast<const half8*>(kb + k_off[ks]);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
+    }
+}
+
+template <bool CAUSAL>
+__device__ __forceinline__ void tile_softmax_pv(const char* vb, const int (&v_off)[2], f32x16& s, const int kt, const int qt,
+                                                const int q, const int L, const int rs, const int hh, const float c,
+                                                float& m, float& lsum, f32x16 (&o)[2]) {
+    const bool need_mask = (kt * 32 + 32 > L) || (CAUSAL && kt == qt);   // wave-uniform
+    if (need_mask) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const bool ok = key < L && (!CAUSAL || key <= q);
+            s[r] = ok ? s[r] : -INFINITY;
+        }
+    }
+    float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+#pragma unroll
+    for (int r = 4; r < 16; r += 4) mx = fmaxf(mx, fmaxf(fmaxf(s[r], s[r + 1]), fmaxf(s[r + 2], s[r + 3])));
+    {      // the other half of the query's keys sits in lane ^ 32: v_permlane32_swap (VALU) instead of an LDS round trip
+        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mx), __builtin_bit_cast(unsigned, mx),
+                                                         false, false);
+        mx = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+    }
+    if (__any(mx > m)) {                 // some query's running max grew: rescale (wave-uniform branch)
+        const float mn = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
+        m = mn;
+        lsum *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
+    const float mc = m * c;
+    half8 pf[2];
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(fmaf(s[r], c, -mc));
+        ps += e;
+        pf[r >> 3][r & 7] = (half_t)e;
+    }
+    lsum += ps;
+    // ---- O^T[d][q] += sum_key V[key][d] P[q][key]; element j of lane half hh is key 16s + 8(j>>2) + 4hh + (j&3)
+    // The transposing reads are inline asm: the compiler's waitcnt pass gives the builtin no memory operand and puts
+    // vmcnt(0) in front of it whenever LDS-DMA is in flight; lgkmcnt is therefore waited here.
+#pragma unroll
+    for (int sstep = 0; sstep < 2; ++sstep) {
+        if (sstep == 1 && kt * 32 + 16 >= rs) break;      // keys beyond the staged rows (all masked): wave-uniform
+        fp16x4_t vr[2][2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const unsigned va = (unsigned)(size_t)(HG_LDS const char*)(vb + sstep * (16 * ROWB) + v_off[dt]);
+            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024"
+                         : "=&v"(vr[dt][0]), "=&v"(vr[dt][1])
+                         : "v"(va)
+                         : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vr[0][0]), "+v"(vr[0][1]), "+v"(vr[1][0]), "+v"(vr[1][1])::"memory");
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            half8 vf;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                vf[e] = (half_t)vr[dt][0][e];
+                vf[4 + e] = (half_t)vr[dt][1][e];
+            }
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[sstep], o[dt], 0, 0, 0);
+        }
+    }
+}
+
+// The same arithmetic in two pieces for the kernel that runs TWO query tiles per wave side by side: tile_softmax() = mask,
+// running maximum / rescale, probabilities (one query tile); tile_pv2() = O^T += V^T P^T for both tiles from ONE set of
+// transposing V reads.  Per tile exactly the operations of tile_softmax_pv(), in the same order: bit-identical.
+template <bool CAUSAL>
+__device__ __forceinline__ void tile_softmax(f32x16& s, const int kt, const int qt, const int q, const int L, const int hh,
+                                             const float c, float& m, float& lsum, f32x16 (&o)[2], half8 (&pf)[2]) {
+    const bool need_mask = (kt * 32 + 32 > L) || (CAUSAL && kt == qt);   // wave-uniform
+    if (need_mask) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const bool ok = key < L && (!CAUSAL || key <= q);
+            s[r] = ok ? s[r] : -INFINITY;
+        }
+    }
+    float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+#pragma unroll
+    for (int r = 4; r < 16; r += 4) mx = fmaxf(mx, fmaxf(fmaxf(s[r], s[r + 1]), fmaxf(s[r + 2], s[r + 3])));
+    {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mx), __builtin_bit_cast(unsigned, mx),
+                                                         false, false);
+        mx = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+    }
+    if (__any(mx > m)) {
+        const float mn = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
+        m = mn;
+        lsum *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
+    const float mc = m * c;
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(fmaf(s[r], c, -mc));
+        ps += e;
+        pf[r >> 3][r & 7] = (half_t)e;
+    }
+    lsum += ps;
+}
+// doA / doB: the tile takes part in this key tile (wave-uniform; a causal tile stops at its diagonal)
+__device__ __forceinline__ void tile_pv2(const char* vb, const int (&v_off)[2], const int kt, const int rs, const bool doA,
+                                         const bool doB, const half8 (&pfA)[2], const half8 (&pfB)[2], f32x16 (&oA)[2],
+                                         f32x16 (&oB)[2]) {
+#pragma unroll
+    for (int sstep = 0; sstep < 2; ++sstep) {
+        if (sstep == 1 && kt * 32 + 16 >= rs) break;
+        fp16x4_t vr[2][2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const unsigned va = (unsigned)(size_t)(HG_LDS const char*)(vb + sstep * (16 * ROWB) + v_off[dt]);
+            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024"
+                         : "=&v"(vr[dt][0]), "=&v"(vr[dt][1])
+                         : "v"(va)
+                         : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vr[0][0]), "+v"(vr[0][1]), "+v"(vr[1][0]), "+v"(vr[1][1])::"memory");
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            half8 vf;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                vf[e] = (half_t)vr[dt][0][e];
+                vf[4 + e] = (half_t)vr[dt][1][e];
+            }
+            if (doA) oA[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pfA[sstep], oA[dt], 0, 0, 0);
+            if (doB) oB[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pfB[sstep], oB[dt], 0, 0, 0);
+        }
+    }
+}
+
+// ROW0: only ONE query of every sequence is wanted - row sel[seq] (row 0 when sel is null): the class token in the
+// last block of the vision tower, the EOT token in the last block of the text tower; the block's other rows never
+// reach the output.  Every wave helps to stage K and V, wave 0 then runs that query (all 32 lanes of the tile alias
+// it) through the same instruction sequence as the full kernel, so the row is bit-identical to the full kernel's; the
+// query comes from the dense matrix q0 [n_seq, D] and the result goes to a dense [n_seq, D] matrix.
+template <bool CAUSAL, bool ROW0>
+__global__ __launch_bounds__(448) void attention_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
+                                                        int L, int heads, int nkt, const half_t* __restrict__ q0,
+                                                        const int32_t* __restrict__ sel, const int mode) {
+    // timing-experiment switches (HG_ATTN_MODE bits 1 no key loop, 2 no K/V staging, 4 no stores, 8 no Q loads; wrong results) exist
+    // only in a -DHG_EXPERIMENTS build
+#ifdef HG_EXPERIMENTS
+    const int xmode = mode;
+#else
+    constexpr int xmode = 0;
+#endif
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // K and V rows 0 .. rs-1 are staged, rs = L rounded up to 16 (the last key tile may be half present: its second
+    // 16-key step is skipped in P V, its missing K rows read into the V region and are masked)
+    const int rs = (L + 15) & ~15;
+    char* Ks = smem;
+    char* Vs = smem + rs * ROWB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int D = heads * HD;
+    const int seq = blockIdx.x / heads, head = blockIdx.x - seq * heads;
+    const size_t ld = (size_t)3 * D;
+    const half_t* base = qkv + (size_t)seq * L * ld + head * HD;
+
+    // ---- stage K and V: piece = 8 rows x 128 B; lane -> (row = l>>3, chunk' = l&7)
+    for (int piece = wave; piece < ((xmode & 2) ? 0 : rs / 8); piece += nwaves) {
+        const int row = piece * 8 + (lane >> 3);
+        const int src_row = row < L ? row : L - 1;
+        const half_t* rp = base + (size_t)src_row * ld;
+        const int cp = lane & 7;
+        glds16(rp + D + ((cp ^ swz_k(row)) << 3), Ks + piece * 1024);
+        glds16(rp + 2 * D + ((cp ^ swz_v(row)) << 3), Vs + piece * 1024);
+    }
+
+    // ---- this wave's query tile; Q fragments straight from global (B operand: lane = query, k = d)
+    int qsel = ROW0 && sel ? __builtin_amdgcn_readfirstlane(sel[seq]) : 0;
+    qsel = qsel < 0 ? 0 : (qsel >= L ? L - 1 : qsel);      // caller error guard, as in layernorm_kernel
+    const int qt = ROW0 ? (qsel >> 5) : wave;
+    const int qcol = lane & 31, hh = lane >> 5;
+    const int q = ROW0 ? qsel : qt * 32 + qcol;
+    // ROW0: every lane's query aliases the sequence's row of the dense q0 matrix (only query 0 is stored)
+    const half_t* qp = ROW0 ? q0 + (size_t)seq * D + head * HD + hh * 8 : base + (size_t)(q < L ? q : L - 1) * ld + hh * 8;
+    half8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        if (xmode & 8) qf[ks] = half8{0, 0, 0, 0, 0, 0, 0, 0};   // timing experiment: no Q loads
+        else qf[ks] = *reinterpret_cast<const half8*>(qp + ks * 16);
+    }
+
+    __syncthreads();   // K/V landed (the barrier's fence waits for the LDS-DMA: vmcnt(0))
+    if constexpr (ROW0) {
+        if (wave != 0) return;
+    }
+
+    // lane-constant LDS offsets
+    int k_off[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) k_off[ks] = qcol * ROWB + (((2 * ks + hh) ^ swz_k(qcol)) << 4);
+    const int gi = lane >> 4, l16 = lane & 15;
+    const int vq = l16 >> 2, vp = l16 & 3;   // tr-read role: row vq of the 4x16 block, columns 4*vp..4*vp+3
+    int v_off[2];
+    {
+        const int key0 = 4 * (gi >> 1) + vq;   // + kt*32 + 16*sstep (+8 for the second read)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const int chunk = dt * 4 + (gi & 1) * 2 + (vp >> 1);
+            v_off[dt] = key0 * ROWB + ((chunk ^ swz_v(key0)) << 4) + (vp & 1) * 8;
+        }
+    }
+
+    const float c = 0.125f * 1.4426950408889634f;   // head_dim^-0.5 * log2(e)
+    float m = -1.0e30f, lsum = 0.f;
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+
+    const int kt_end = (xmode & 1) ? 0 : (CAUSAL ? (qt + 1 < nkt ? qt + 1 : nkt) : nkt);
+    for (int kt = 0; kt < kt_end; ++kt) {
+        f32x16 sc;
+        tile_scores(Ks + kt * TILEB, k_off, qf, sc);
+        tile_softmax_pv<CAUSAL>(Vs + kt * TILEB, v_off, sc, kt, qt, q, L, rs, hh, c, m, lsum, o);
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    const float inv = 1.0f / lsum;
+    // ---- store: lane = query q, d = dt*32 + (r&3) + 8*(r>>2) + 4*hh
+    if constexpr (ROW0) {
+        if (qcol == 0 && !(xmode & 4)) {
+            half_t* op = out + (size_t)seq * D + head * HD;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    half4 h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[e] = (half_t)(o[dt][g * 4 + e] * inv);
+                    *reinterpret_cast<half4*>(op + dt * 32 + 8 * g + 4 * hh) = h;
+                }
+        }
+    } else {
+        // Row-per-lane 8-byte stores touch 32 cache lines per instruction (29 us of a 100 us kernel); instead the
+        // wave's 32 x 64 tile goes through LDS (the K/V rows are dead once every wave has left the key loop; 16-byte
+        // chunks XOR-swizzled by row) and leaves as whole 128-byte rows: lane -> (row = l >> 3, chunk = l & 7).
+        __syncthreads();
+        char* ot = smem + wave * 4096;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                half4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = (half_t)(o[dt][g * 4 + e] * inv);
+                *reinterpret_cast<half4*>(ot + qcol * 128 + (((dt * 4 + g) ^ (qcol & 7)) << 4) + hh * 8) = h;
+            }
+        const int cr = lane >> 3, cc = lane & 7;
+#pragma unroll
+        for (int rb = 0; rb < 32; rb += 8) {
+            const int row = rb + cr, qq = qt * 32 + row;
+            const half8 v = *reinterpret_cast<const half8*>(ot + row * 128 + ((cc ^ (row & 7)) << 4));
+            if (qq < L && !(xmode & 4))
+                *reinterpret_cast<half8*>(out + ((size_t)seq * L + qq) * D + head * HD + cc * 8) = v;
+        }
+    }
+}
+
+// Two query tiles per wave (QPW = 2): four waves instead of seven for L = 197, so that THREE workgroups fit a CU (3 x 52 KiB of
+// LDS, 12 waves: no register cap) and the load / key-loop / store phases of three (sequence, head) items overlap instead of
+// two (round 2 reached three only with an 80-VGPR cap that spilled).  Wave w runs query tiles w and w + nwaves SIDE BY SIDE:
+// every K and V fragment read from LDS feeds both tiles' MFMAs (half the LDS traffic) and the two softmax dependency chains
+// interleave; per tile the arithmetic is the one-tile kernel's - the same bits.  Both tiles leave through LDS as whole rows
+// once every wave has left its key loop.
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 3) void attention_kernel_q2(const half_t* __restrict__ qkv, half_t* __restrict__ out, int L,
+                                                           int heads, int nkt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int rs = (L + 15) & ~15;
+    char* Ks = smem;
+    char* Vs = smem + rs * ROWB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int D = heads * HD;
+    const int seq = blockIdx.x / heads, head = blockIdx.x - seq * heads;
+    const size_t ld = (size_t)3 * D;
+    const half_t* base = qkv + (size_t)seq * L * ld + head * HD;
+
+    for (int piece = wave; piece < rs / 8; piece += nwaves) {
+        const int row = piece * 8 + (lane >> 3);
+        const int src_row = row < L ? row : L - 1;
+        const half_t* rp = base + (size_t)src_row * ld;
+        const int cp = lane & 7;
+        glds16(rp + D + ((cp ^ swz_k(row)) << 3), Ks + piece * 1024);
+        glds16(rp + 2 * D + ((cp ^ swz_v(row)) << 3), Vs + piece * 1024);
+    }
+    const int qcol = lane & 31, hh = lane >> 5;
+    half8 qf[2][4];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int qt = wave + it * nwaves;
+        const int q = qt * 32 + qcol;
+        const half_t* qp = base + (size_t)(q < L ? q : L - 1) * ld + hh * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[it][ks] = *reinterpret_cast<const half8*>(qp + ks * 16);
+    }
+    __syncthreads();   // K/V landed
+
+    int k_off[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) k_off[ks] = qcol * ROWB + (((2 * ks + hh) ^ swz_k(qcol)) << 4);
+    const int gi = lane >> 4, l16 = lane & 15;
+    const int vq = l16 >> 2, vp = l16 & 3;
+    int v_off[2];
+    {
+        const int key0 = 4 * (gi >> 1) + vq;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const int chunk = dt * 4 + (gi & 1) * 2 + (vp >> 1);
+            v_off[dt] = key0 * ROWB + ((chunk ^ swz_v(key0)) << 4) + (vp & 1) * 8;
+        }
+    }
+    const float c = 0.125f * 1.4426950408889634f;
+    half4 oh[2][8];                              // normalised outputs of the wave's two tiles: [tile][dt*4 + g]
+    {
+        const int qtA = wave, qtB = wave + nwaves;
+        const bool hasB = qtB < nkt;
+        const int qA = qtA * 32 + qcol, qB = qtB * 32 + qcol;
+        float mA = -1.0e30f, lA = 0.f, mB = -1.0e30f, lB = 0.f;
+        f32x16 oA[2], oB[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { oA[dt][r] = 0.f; oB[dt][r] = 0.f; }
+        const int endA = CAUSAL ? (qtA + 1 < nkt ? qtA + 1 : nkt) : nkt;
+        const int endB = hasB ? (CAUSAL ? (qtB + 1 < nkt ? qtB + 1 : nkt) : nkt) : 0;
+        const int end = endA > endB ? endA : endB;
+        for (int kt = 0; kt < end; ++kt) {
+            const bool doA = kt < endA, doB = kt < endB;
+            // S^T of both tiles from ONE set of K fragment reads
+            f32x16 sA, sB;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sA[r] = 0.f; sB[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const half8 kf = *reinterpret_cast<const half8*>(Ks + kt * TILEB + k_off[ks]);
+                if (doA) sA = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[0][ks], sA, 0, 0, 0);
+                if (doB) sB = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[1][ks], sB, 0, 0, 0);
+            }
+            half8 pfA[2], pfB[2];
+            if (doA) tile_softmax<CAUSAL>(sA, kt, qtA, qA, L, hh, c, mA, lA, oA, pfA);
+            if (doB) tile_softmax<CAUSAL>(sB, kt, qtB, qB, L, hh, c, mB, lB, oB, pfB);
+            tile_pv2(Vs + kt * TILEB, v_off, kt, rs, doA, doB, pfA, pfB, oA, oB);
+        }
+        lA += __shfl_xor(lA, 32, 64);
+        lB += __shfl_xor(lB, 32, 64);
+        const float invA = 1.0f / lA, invB = 1.0f / lB;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    oh[0][dt * 4 + g][e] = (half_t)(oA[dt][g * 4 + e] * invA);
+                    oh[1][dt * 4 + g][e] = (half_t)(oB[dt][g * 4 + e] * invB);
+                }
+    }
+    // ---- store through LDS as whole 128-byte rows (the K/V rows are dead once every wave has left its key loops)
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int qt = wave + it * nwaves;
+        if (qt < nkt) {
+            char* ot = smem + qt * 4096;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                *reinterpret_cast<half4*>(ot + qcol * 128 + ((j ^ (qcol & 7)) << 4) + hh * 8) = oh[it][j];
+            const int cr = lane >> 3, cc = lane & 7;
+#pragma unroll
+            for (int rb = 0; rb < 32; rb += 8) {
+                const int row = rb + cr, qq = qt * 32 + row;
+                const half8 v = *reinterpret_cast<const half8*>(ot + row * 128 + ((cc ^ (row & 7)) << 4));
+                if (qq < L) *reinterpret_cast<half8*>(out + ((size_t)seq * L + qq) * D + head * HD + cc * 8) = v;
+            }
+        }
+    }
+}
+
+template <bool CAUSAL, bool ROW0 = false>
+static hipError_t launch_t(const half_t* qkv, half_t* out, int n_seq, int L, int heads, hipStream_t s,
+                           const half_t* q0 = nullptr, const int32_t* sel = nullptr) {
+    const int nkt = (L + 31) / 32;
+    const int lds = 2 * ((L + 15) & ~15) * ROWB;
+    static bool attr_set_d[HG_MAX_DEVICES] = {};      // function attributes are per device
+    bool& attr_set = attr_set_d[current_device_index()];
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<CAUSAL, ROW0>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 7 * TILEB);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    static const int mode = getenv("HG_ATTN_MODE") ? atoi(getenv("HG_ATTN_MODE")) : 0;   // read by experiment builds only
+    if constexpr (!ROW0) {
+        // HG_ATTN_QPW=1: one query tile per wave (seven waves at L = 197, two workgroups per CU)
+        static const int qpw = []() { const char* e = getenv("HG_ATTN_QPW"); return e ? atoi(e) : 2; }();
+        if (qpw == 2 && nkt >= 2) {
+            static bool attr2_d[HG_MAX_DEVICES] = {};
+            bool& attr2 = attr2_d[current_device_index()];
+            if (!attr2) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel_q2<CAUSAL>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 7 * TILEB);
+                if (e != hipSuccess) return e;
+                attr2 = true;
+            }
+            hipLaunchKernelGGL((attention_kernel_q2<CAUSAL>), dim3(n_seq * heads), dim3(64 * ((nkt + 1) / 2)), lds, s, qkv, out, L,
+                               heads, nkt);
+            return hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL((attention_kernel<CAUSAL, ROW0>), dim3(n_seq * heads), dim3(64 * nkt), lds, s, qkv, out, L, heads, nkt, q0, sel,
+                       mode);
+    return hipGetLastError();
+}
+
+hipError_t launch_attention(const half_t* qkv, half_t* out, int n_seq, int L, int heads, bool causal,
+                            hipStream_t s) {
+    if (n_seq <= 0) return hipSuccess;
+    if (L < 1 || L > 224) return hipErrorInvalidValue;
+    return causal ? launch_t<true>(qkv, out, n_seq, L, heads, s) : launch_t<false>(qkv, out, n_seq, L, heads, s);
+}
+
+hipError_t launch_attention_row0(const half_t* qkv, const half_t* q0, const int32_t* sel, half_t* out, int n_seq, int L,
+                                 int heads, bool causal, hipStream_t s) {
+    if (n_seq <= 0) return hipSuccess;
+    if (L < 1 || L > 224 || !q0) return hipErrorInvalidValue;
+    return causal ? launch_t<true, true>(qkv, out, n_seq, L, heads, s, q0, sel)
+                  : launch_t<false, true>(qkv, out, n_seq, L, heads, s, q0, sel);
+}
+
+}  // namespace hg
