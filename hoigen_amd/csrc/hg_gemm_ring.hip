@@ -1000,6 +1000,10 @@ hipError_t launch_gemm_ring(int epi, const GemmArgs& a, hipStream_t s) {
     const int rounds = (t256 + 255) / 256, rounds128 = (t128 + 255) / 256;
     static const int force_big = []() { const char* e = getenv("HG_RING_BIG"); return e ? atoi(e) : 0; }();
     bool big = t256 >= 256 && (double)t256 / (rounds * 256.0) >= 0.9;
+    // ... or when its whole passes (even rounds: launch_ring_t uses only as many workgroups as fill them) still beat the
+    // 128-row kernel's: text-tower QKV, M = 46 200, N = 1536: 5 passes of 256x256 against 8.5 of 128x256 at ~0.8 of the time
+    // each (80 -> 73 us, round 3)
+    if (!resid && !big && t256 >= 256 && (double)rounds <= 0.8 * (double)t128 / 256.0) big = true;
     // ... measured at N = 768, M = 50432: plain residual 272 vs 298 us (K = 3072).  With the LayerNorm extras
     // (fp16 copy + statistics: 387 MB per launch) the epilogue is an HBM burst of every CU at once, and three big
     // bursts overlap worse than five small ones (K = 768: 154 vs 127 us; K = 3072: 300 vs 303): keep 128 rows.
