@@ -67,8 +67,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                                                     const unsigned a_bytes, const int mode, const int gsz) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins (buffer resources, LDS DMA): host sees just the stub
     // timing-experiment switches (HG_RING_MODE bits 1 locality, 2 no MFMA, 4 no epilogue, 8 no stagger, 32 no fragment
-    // reads, 64 no operand DMA, 128 no fp16 stores, 16 one junk store per K-tile into the previous tile) exist only in a -DHG_EXPERIMENTS build: run-time branches in the K
-    // loop cost several per cent
+    // reads, 64 no operand DMA) exist only in a -DHG_EXPERIMENTS build: run-time branches in the K loop cost several per
+    // cent.  (The store experiments of round 2 - junk stores trickled under the next tile, epilogue without stores - are in
+    // the history: commits "Ring2 junk-trickle experiment", "experiment: phase-shifted half tiles"; results in DESIGN.md 4.)
 #ifdef HG_EXPERIMENTS
     const int xmode = mode;
 #else
@@ -374,17 +375,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     // the previous tile lay inside M, i.e. issued every one of its E epilogue stores (a ragged tile may skip store
     // instructions whose rows are all masked: the waits that follow it then do not allow for any)
     bool prev_full = false;
-    int trk_m0 = 0, trk_n0 = 0;
     for (int r = 0; r < my_tiles; ++r) {
         int tm, tn;
         tile_of(slot + r * cpx, tm, tn);
         const int m0 = tm * BM, n0 = tn * 256;
         const bool post_ok = prev_full;
         prev_full = m0 + BM <= p.M;
-        const int trickle_m0 = trk_m0, trickle_n0 = trk_n0;     // the previous tile (HG_RING_MODE bit 16 experiment)
-        trk_m0 = m0 + BM <= p.M ? m0 : 0;
-        trk_n0 = n0;
-        (void)trickle_m0; (void)trickle_n0;
         zero_acc();
         f32x4 xres[XPRE ? 2 : 1][XPRE ? 2 : 1][XPRE ? MF : 1][XPRE ? 2 : 1];
         // rolling residual window (ROLL): chunk c = ((ha * MF + f) * 2 + hb) * 2 + g2 is this lane's f32x4 of row
@@ -461,16 +457,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             mma(I0{}, I0{});
             mma(I0{}, I1{});
             sync_mma();
-            if constexpr (F16_STORES) {
-                if ((xmode & 16) && r > 0) {   // timing experiment: the previous tile's output trickles out, one 1-KiB store per K-tile
-                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                    const u32x4 junk = {(unsigned)lane, 1u, 2u, 3u};
-                    half_t* tp = reinterpret_cast<half_t*>(p.out) + (size_t)(trickle_m0 + wm * 128 + ((g * 8) & 127) + (lane >> 3)) * p.ldc +
-                                 trickle_n0 + wn * 64 + (lane & 7) * 8;
-                    *reinterpret_cast<u32x4*>(tp) = junk;
-                    if ((g & 3) == 0) *reinterpret_cast<u32x4*>(tp + (size_t)64 * p.ldc) = junk;
-                }
-            }
             read_A(1, buf);
             if (KIND < 2 || more) { ld_advance(std::integral_constant<int, KIND == 2 ? 1 : 0>{}); issue_A(0, 0, GA); issue_W(0, 0, GB); issue_W(1, 0, GB); }
             SEG_B(0);
@@ -667,12 +653,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                         st1[j] = low ? recv : d[4 + j];
                     }
                     const int row0 = mb + (r16 & 7);
-                    if (xmode & 128) {   // timing experiment: epilogue arithmetic without the stores
-                        asm volatile("" ::"v"(st0), "v"(st1));
-                    } else {
-                        if (INTERIOR || row0 < p.M) *reinterpret_cast<u32x4*>(colp + (size_t)row0 * p.ldc) = st0;
-                        if (INTERIOR || row0 + 8 < p.M) *reinterpret_cast<u32x4*>(colp + (size_t)(row0 + 8) * p.ldc) = st1;
-                    }
+                    if (INTERIOR || row0 < p.M) *reinterpret_cast<u32x4*>(colp + (size_t)row0 * p.ldc) = st0;
+                    if (INTERIOR || row0 + 8 < p.M) *reinterpret_cast<u32x4*>(colp + (size_t)(row0 + 8) * p.ldc) = st1;
                 }
             };
             if (m0 + BM <= p.M) f16_epilogue(std::true_type{});

@@ -43,9 +43,10 @@ template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int tiles_n, const int n_tiles,
                                                      const unsigned a_bytes, const int mode, const int gsz) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins (buffer resources, LDS DMA): host sees just the stub
-    // timing-experiment switches (HG_RING_MODE bits 1 locality, 2 no MFMA, 4 no epilogue, 8 no stagger, 16 coalesced
-    // stores, 64 no operand DMA, 32 (with 4) a tile's residual read-modify-write as junk loads / stores under the next
-    // tile's K loop) exist only in a -DHG_EXPERIMENTS build: run-time branches in the K loop cost several per cent
+    // timing-experiment switches (HG_RING_MODE bits 1 locality, 2 no MFMA, 4 no epilogue, 8 no stagger, 64 no operand DMA)
+    // exist only in a -DHG_EXPERIMENTS build: run-time branches in the K loop cost several per cent.  (Round 2's store
+    // experiments - lane-linear stores, a tile's read-modify-write trickled under the next tile's K loop as junk accesses -
+    // are in the history; results in DESIGN.md 4.)
 #ifdef HG_EXPERIMENTS
     const int xmode = mode;
 #else
@@ -274,11 +275,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
 #ifdef HG_STAMPS
     t_all = __builtin_amdgcn_s_memtime();
 #endif
-    int g = 0, stg = 0;                        // K-tile position in the stream and its LDS stage (g % NST)
+    int stg = 0;                               // LDS stage of the current K-tile of the stream (position % NST)
     // the previous tile lay inside M, i.e. issued every one of its E epilogue stores (a ragged tile may skip store
     // instructions whose rows are all masked: the waits that follow it then do not allow for any)
     bool prev_full = false;
-    int tkp_m0 = 0, tkp_n0 = 0;
     for (int r = 0; r < my_tiles; ++r) {
         int tm, tn;
         tile_of(slot + r * cpx, tm, tn);
@@ -294,12 +294,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
 #pragma unroll
                     for (int g2 = 0; g2 < 2; ++g2) acc[a][b][f][g2] = f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 xres[RESID ? 2 : 1][RESID ? 2 : 1][RESID ? 2 : 1][RESID ? 2 : 1];
-        f32x4 tkeep0 = {0.f, 0.f, 0.f, 0.f}, tkeep1 = tkeep0;   // experiment bit 32
-        int tkn = 0;
-        const int tk_m0 = tkp_m0, tk_n0 = tkp_n0;
-        tkp_m0 = m0 + BM <= p.M ? m0 : 0;
-        tkp_n0 = n0;
-        (void)tk_m0; (void)tk_n0; (void)tkn;
         float muv[RLN ? 2 : 1][RLN ? 2 : 1];          // EPI_RESID_LN: centre of this lane's rows for the fp16 copy
         // One K-tile.  KIND: 0 middle, 1 first of a tile (the previous epilogue's stores may be pending), 2 / 3 / 4 the
         // third-to-last, second-to-last and last K-tile of a tile: only there the refills (A at distance 2, W at
@@ -328,13 +322,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
 #pragma unroll
                                 for (int g2 = 0; g2 < 2; ++g2) {
                                     const int n = n0 + hb * 128 + wn * 32 + g2 * 16 + 4 * (lane >> 4);
-                                    if (xmode & 16) {
-                                        const int idx = ((ha * 2 + f) * 2 + hb) * 2 + g2;
-                                        int rr = m0 + wave * 16 + idx;
-                                        rr = rr < p.M ? rr : p.M - 1;
-                                        xres[ha][hb][f][g2] = *reinterpret_cast<const f32x4*>(
-                                            reinterpret_cast<const float*>(p.out) + (size_t)rr * p.ldc + n0 + lane * 4);
-                                    } else
                                     xres[ha][hb][f][g2] = *reinterpret_cast<const f32x4*>(
                                         reinterpret_cast<const float*>(p.out) + (size_t)m * p.ldc + n);
                                 }
@@ -344,37 +331,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
             sync_fetch();
             mma(I0{});
             sync_mma();
-            if constexpr (RLN && KIND == 0) {
-                if ((xmode & 32) && r > 0 && tkn < 8) {   // timing experiment (with bit 4): a tile's read-modify-write trickles out
-                    ++tkn;                                 // under the next tile's K loop: 2 row loads + 4 stores per K-tile
-                    float* xo = reinterpret_cast<float*>(p.out);
-                    f32x4 t0, t1;
-                    const f32x4 junk = {1.f, 2.f, 3.f, 4.f};
-                    if (xmode & 128) {      // whole-line variant: every instruction covers 4 rows x 256 B (fp32) / 8 rows x 128 B (fp16)
-                        const size_t l0 = (size_t)(tk_m0 + wm * 64 + (tkn - 1) * 8 + (lane >> 4)) * p.ldc + tk_n0 + wn * 64 + (lane & 15) * 4;
-                        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off"
-                                     : "=&v"(t0), "=&v"(t1) : "v"(xo + l0), "v"(xo + l0 + (size_t)4 * p.ldc) : "memory");
-                        *reinterpret_cast<f32x4*>(xo + l0) = junk;
-                        *reinterpret_cast<f32x4*>(xo + l0 + (size_t)4 * p.ldc) = junk;
-                        *reinterpret_cast<f32x4*>(xo + l0) = junk;
-                        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(p.out2) + ((size_t)(tk_m0 + wm * 64 + (tkn - 1) * 8 + (lane >> 3)) * p.ldc + tk_n0 + wn * 64) * 2 + (lane & 7) * 16) = junk;
-                    } else {
-                    const size_t o0 = (size_t)(tk_m0 + wm * 32 + (lane & 15)) * p.ldc + tk_n0 + wn * 32 + 4 * (lane >> 4) + (tkn & 1) * 128;
-                    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:64"
-                                 : "=&v"(t0), "=&v"(t1) : "v"(xo + o0 + (size_t)(tkn >> 1) * 16 * p.ldc) : "memory");
-                    *reinterpret_cast<f32x4*>(xo + o0 + (size_t)(64 + (tkn >> 1) * 16) * p.ldc) = junk;
-                    *reinterpret_cast<f32x4*>(xo + o0 + (size_t)(64 + (tkn >> 1) * 16) * p.ldc + 16) = junk;
-                    *reinterpret_cast<f32x4*>(xo + o0 + (size_t)(64 + (tkn >> 1) * 16) * p.ldc + 32) = junk;
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(p.out2) + ((size_t)(tk_m0 + wm * 32 + (lane & 15) + (tkn >> 1) * 16) * p.ldc + tk_n0 + wn * 32) * 2 + (lane >> 4) * 16) = junk;
-                    }
-                    tkeep0 = t0; tkeep1 = t1;
-                }
-            }
             // ---------------- PB: fetch A1; refill W(g+3); wait for A,W(g+1); quadrants (A1,W0) (A1,W1)
             read_A(1, st);
             if (KIND < 2 || more) issue_W(std::integral_constant<int, KIND == 2 ? 1 : 0>{});   // K-tile g+3 exists
             SEG_B(0);
-            if constexpr (KIND == 0) { if (RLN && (xmode & 32) && r > 0 && tkn <= 8 && tkn > 0) { wait_vm<NWT + 6>(); asm volatile("" ::"v"(tkeep0), "v"(tkeep1)); } else wait_vm<NWT>(); }
+            if constexpr (KIND == 0) wait_vm<NWT>();
             else if constexpr (KIND == 1) { if (post_ok) wait_vm<NWT + E>(); else wait_vm<NWT>(); }
             else if constexpr (KIND == 4) { if (more) wait_vm<NWT + R>(); }       // no successor: nothing to wait for
             else { if (more) wait_vm<NWT>(); else wait_vm<0>(); }
@@ -382,7 +343,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
             sync_fetch();
             mma(I1{});
             sync_mma();
-                    ++g;
         };
         {
             using K0 = std::integral_constant<int, 0>;
@@ -521,13 +481,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                             const int n = n0 + hb * 128 + wn * 32 + g2 * 16 + 4 * q;
                             f32x4 v = acc[ha][hb][f][g2] + *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + n * 4);
                             if constexpr (RESID) {
-                                if (xmode & 16) {
-                                    const int idx = ((ha * 2 + f) * 2 + hb) * 2 + g2;
-                                    const int rr = m0 + wave * 16 + idx;
-                                    if (rr < p.M)
-                                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)rr * p.ldc + n0 + lane * 4) =
-                                            xres[ha][hb][f][g2] + v;
-                                } else
                                 if (INTERIOR || m < p.M) {
                                     if constexpr (EPI == EPI_SCALE_RESID_F32) v *= *reinterpret_cast<const f32x4*>(p.pos + n);
                                     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) =
