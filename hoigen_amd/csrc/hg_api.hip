@@ -514,11 +514,12 @@ bool ln_fuse_ok(hg_ctx* c, int M, int D) {
 // [n_seq, D] stream, returned through *row0_out); all other rows of that block never reach any output.
 // HG_LAST_BLOCK_ROW0=0 runs the last block on every row like the others.
 // `pre_w` / `pre_b` (vision tower): the LayerNorm in front of the first block (ln_pre) has NOT been applied yet; it runs
-// here, fused with the first block's folding statistics when folding is on
+// here, fused with the first block's folding statistics when folding is on - and, with `pre_pos` / `pre_cls`, with the class
+// rows and the positional embedding the patch GEMM left out (clipnet/model.py:223-225 in one pass over the rows)
 int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, int D, int heads, bool causal,
                hipStream_t s, float* trace, int trace_stride, const AdapterCall* ac, bool ln_fold,
                const float** row0_out = nullptr, const int32_t* sel = nullptr, const float* pre_w = nullptr,
-               const float* pre_b = nullptr) {
+               const float* pre_b = nullptr, const float* pre_pos = nullptr, const float* pre_cls = nullptr) {
     const int M = n_seq * L;
     const char* row0_e = getenv("HG_LAST_BLOCK_ROW0");      // read per call: the tests switch it
     const bool row0_env = !(row0_e && row0_e[0] == '0');
@@ -558,10 +559,10 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         mu = (float*)c->mu.p;
         muc = adapters ? (float*)c->muc.p : nullptr;
         stats = (float*)c->stats.p;
-        if (pre_w) HG_HIP(launch_layernorm_rowstats(x, pre_w, pre_b, h, mr, mu, muc, M, D, s));
+        if (pre_w) HG_HIP(launch_layernorm_rowstats(x, pre_w, pre_b, h, mr, mu, muc, M, D, s, pre_pos, pre_cls, L));
         else HG_HIP(launch_rowstats_cast(x, h, mr, mu, M, D, s, muc));
     } else if (pre_w) {
-        HG_HIP(launch_layernorm_f32(x, pre_w, pre_b, x, M, D, s));
+        HG_HIP(launch_layernorm_f32(x, pre_w, pre_b, x, M, D, s, pre_pos, pre_cls, L));
     }
     if (pre_w && trace) HG_HIP(launch_copy_rows(x, trace, n_seq, L, D, s));
     for (size_t i = 0; i < blocks.size(); ++i) {
@@ -1328,9 +1329,9 @@ static int encode_image_impl(hg_ctx* c, const float* x_nchw, const float* priors
         HG_HIP(launch_im2col(x_nchw + (size_t)b0 * img, patches, Bc, v.res, v.patch, s));
         GemmArgs g{};
         g.A = patches; g.lda = v.Kp; g.W = v.w_patch; g.bias = nullptr; g.out = x; g.ldc = D;
-        g.M = Bc * G; g.N = D; g.K = v.Kp; g.pos = v.pos; g.G = G; g.L = L;
+        // class rows, positional embedding and ln_pre are one pass over the rows (run_blocks): the GEMM only scatters
+        g.M = Bc * G; g.N = D; g.K = v.Kp; g.pos = nullptr; g.G = G; g.L = L;
         HG_HIP(gemm(c, EPI_PATCH_F32, g, s));
-        HG_HIP(launch_cls_rows(x, v.cls, v.pos, Bc, L, D, s));
         float* tr = trace ? trace + (size_t)b0 * D : nullptr;      // (row 0 of the trace = after ln_pre: copied inside run_blocks)
         const int tstride = B * D;
         AdapterCall ac;
@@ -1340,7 +1341,7 @@ static int encode_image_impl(hg_ctx* c, const float* x_nchw, const float* priors
         ac.N = N;
         const float* row0 = nullptr;      // dense class-token rows when the last block ran on them only
         rc = run_blocks(c, v.blocks, Bc, L, D, v.heads, false, s, tr, tstride, &ac, true, variant_c ? nullptr : &row0, nullptr,
-                        v.lnpre_w, v.lnpre_b);
+                        v.lnpre_w, v.lnpre_b, v.pos, v.cls);
         if (rc) return rc;
         half_t* h16 = (half_t*)c->head16.p;
         if (!variant_c) {

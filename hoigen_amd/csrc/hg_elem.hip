@@ -12,7 +12,8 @@ template <typename OutT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, OutT* __restrict__ out, int M,
                                                         int D, const int32_t* __restrict__ gather, int rows_per_seq,
-                                                        int in_row_mul) {
+                                                        int in_row_mul, const float* __restrict__ pos = nullptr,
+                                                        const float* __restrict__ cls = nullptr, int Lpos = 1) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= M) return;
@@ -23,7 +24,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         in_row = (size_t)r * rows_per_seq + gidx;
     }
     else in_row = (size_t)r * in_row_mul;
-    const f32x4* xp = reinterpret_cast<const f32x4*>(x + in_row * D);
+    // ln_pre of the vision tower (pos != nullptr): the row is [cls ; patch embedding] + pos[t] (clipnet/model.py:223-224) -
+    // the class row (t = 0) comes from cls, the patch GEMM left the other rows without their positional embedding
+    const int tpos = pos ? r % Lpos : 0;
+    const f32x4* xp = reinterpret_cast<const f32x4*>((pos && tpos == 0) ? cls : x + in_row * D);
+    const f32x4* pp = reinterpret_cast<const f32x4*>(pos ? pos + (size_t)tpos * D : nullptr);
     const int nc = D >> 2;
     f32x4 v[LN_MAXC];
     float s = 0.f;
@@ -32,6 +37,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         const int c = lane + 64 * i;
         if (c < nc) {
             v[i] = xp[c];
+            if (pos) v[i] += pp[c];
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
     }
@@ -80,11 +86,11 @@ hipError_t launch_layernorm_f16(const float* x, const float* w, const float* b, 
     return hipGetLastError();
 }
 hipError_t launch_layernorm_f32(const float* x, const float* w, const float* b, float* out, int M, int D,
-                                hipStream_t s) {
+                                hipStream_t s, const float* pos, const float* cls, int L) {
     if (M <= 0) return hipSuccess;
-    if (D % 4 || D > 256 * LN_MAXC) return hipErrorInvalidValue;
+    if (D % 4 || D > 256 * LN_MAXC || (pos && (!cls || L < 1))) return hipErrorInvalidValue;
     hipLaunchKernelGGL(layernorm_kernel<float>, dim3((M + 3) / 4), dim3(256), 0, s, x, w, b, out, M, D,
-                       (const int32_t*)nullptr, 0, 1);
+                       (const int32_t*)nullptr, 0, 1, pos, cls, L);
     return hipGetLastError();
 }
 
@@ -123,18 +129,6 @@ hipError_t launch_im2col(const float* x, half_t* out, int B, int R, int p, hipSt
     return hipGetLastError();
 }
 
-__global__ void cls_rows_kernel(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos,
-                                int B, int L, int D) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= B * D) return;
-    const int b = i / D, d = i - b * D;
-    x[(size_t)b * L * D + d] = cls[d] + pos[d];
-}
-hipError_t launch_cls_rows(float* x, const float* cls, const float* pos, int B, int L, int D, hipStream_t s) {
-    if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(cls_rows_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, x, cls, pos, B, L, D);
-    return hipGetLastError();
-}
 
 // ---- text embedding: x = token_embedding[ids] + positional (clipnet/model.py:340-342) ------------
 __global__ __launch_bounds__(256) void embed_tokens_kernel(const int32_t* __restrict__ ids, int ld_ids,
@@ -563,11 +557,17 @@ __global__ __launch_bounds__(256) void rowstats_cast_kernel(const float* __restr
 __global__ __launch_bounds__(256) void layernorm_rowstats_kernel(float* __restrict__ x, const float* __restrict__ w,
                                                                  const float* __restrict__ b, half_t* __restrict__ x16,
                                                                  float* __restrict__ mr, float* __restrict__ mu,
-                                                                 float* __restrict__ muc, int M, int D) {
+                                                                 float* __restrict__ muc, int M, int D,
+                                                                 const float* __restrict__ pos, const float* __restrict__ cls,
+                                                                 int Lpos) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= M) return;
     f32x4* xp = reinterpret_cast<f32x4*>(x + (size_t)r * D);
+    // pos != nullptr: the row is [cls ; patch embedding] + pos[t] first (see layernorm_kernel)
+    const int tpos = pos ? r % Lpos : 0;
+    const f32x4* xin = (pos && tpos == 0) ? reinterpret_cast<const f32x4*>(cls) : xp;
+    const f32x4* pp = reinterpret_cast<const f32x4*>(pos ? pos + (size_t)tpos * D : nullptr);
     const int nc = D >> 2;
     f32x4 v[LN_MAXC];
     float s = 0.f;
@@ -575,7 +575,8 @@ __global__ __launch_bounds__(256) void layernorm_rowstats_kernel(float* __restri
     for (int i = 0; i < LN_MAXC; ++i) {
         const int c = lane + 64 * i;
         if (c < nc) {
-            v[i] = xp[c];
+            v[i] = xin[c];
+            if (pos) v[i] += pp[c];
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
     }
@@ -632,10 +633,10 @@ __global__ __launch_bounds__(256) void layernorm_rowstats_kernel(float* __restri
     }
 }
 hipError_t launch_layernorm_rowstats(float* x, const float* w, const float* b, half_t* x16, float* mr, float* mu, float* muc,
-                                     int M, int D, hipStream_t s) {
+                                     int M, int D, hipStream_t s, const float* pos, const float* cls, int L) {
     if (M <= 0) return hipSuccess;
-    if (D % 4 || D > 256 * LN_MAXC) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(layernorm_rowstats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, w, b, x16, mr, mu, muc, M, D);
+    if (D % 4 || D > 256 * LN_MAXC || (pos && (!cls || L < 1))) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_rowstats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, w, b, x16, mr, mu, muc, M, D, pos, cls, L);
     return hipGetLastError();
 }
 hipError_t launch_rowstats_cast(const float* x, half_t* x16, float* mr, float* mu, int M, int D, hipStream_t s, float* muc) {

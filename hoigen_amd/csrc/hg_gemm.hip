@@ -73,9 +73,9 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, int m, int n, f32x4 
         *reinterpret_cast<f32x4*>(dst) = v;
     } else if constexpr (EPI == EPI_PATCH_F32) {
         const int b = m / p.G, t = m - b * p.G;
-        const f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (size_t)(1 + t) * p.N + n);
+        if (p.pos) v += *reinterpret_cast<const f32x4*>(p.pos + (size_t)(1 + t) * p.N + n);
         const size_t orow = (size_t)b * p.L + 1 + t;
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + orow * p.ldc + n) = v + pe;
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + orow * p.ldc + n) = v;
     }
 }
 

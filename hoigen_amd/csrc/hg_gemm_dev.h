@@ -77,8 +77,10 @@ __device__ __forceinline__ void epilogue_ring(const GemmArgs& p, int m, int n, f
         *reinterpret_cast<f32x4*>(dst) = v;
     } else if constexpr (EPI == EPI_PATCH_F32) {
         const int b = m / p.G, t = m - b * p.G;
-        const f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (size_t)(1 + t) * p.N + n);
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + ((size_t)b * p.L + 1 + t) * p.ldc + n) = v + pe;
+        // pos == nullptr (the product path): the positional embedding is added by the ln_pre kernel, which reads the rows
+        // anyway - a register-returning global load here waits for every older DMA of the ring
+        if (p.pos) v += *reinterpret_cast<const f32x4*>(p.pos + (size_t)(1 + t) * p.N + n);
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + ((size_t)b * p.L + 1 + t) * p.ldc + n) = v;
     }
 }
 

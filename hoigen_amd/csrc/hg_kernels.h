@@ -14,7 +14,7 @@ enum Epilogue : int {
     EPI_BIAS_RELU_F16 = 2,   // out fp16 = relu(acc + bias)
     EPI_BIAS_RESID_F32 = 3,  // out fp32 += acc + bias   (residual stream, in place)
     EPI_BIAS_F32 = 4,        // out fp32 = acc + bias (bias may be null)
-    EPI_PATCH_F32 = 5,       // patch embedding: row m=(b,t) -> out row b*L+1+t, + pos[1+t]
+    EPI_PATCH_F32 = 5,       // patch embedding: row m=(b,t) -> out row b*L+1+t (+ pos[1+t] when GemmArgs::pos is given)
     EPI_BIAS_RELU_F32 = 6,   // out fp32 = relu(acc + bias)
     EPI_SCALE_RESID_F32 = 7, // out fp32 += (acc + bias) * pos[n]   (adapter up_proj * scale, residual)
     // LayerNorm folded into the GEMM (ring kernels only): A = raw fp16 copy of the residual rows, W = gamma-folded
@@ -94,12 +94,11 @@ hipError_t launch_attention_row0(const half_t* qkv, const half_t* q0, const int3
 // Input row for output row r:  gather ? r*rows_per_seq + gather[r] : r*in_row_stride_rows.
 hipError_t launch_layernorm_f16(const float* x, const float* w, const float* b, half_t* out, int M, int D,
                                 const int32_t* gather, int rows_per_seq, int in_row_mul, hipStream_t s);
+// pos / cls / L (ln_pre of the vision tower): row r is first replaced by (r % L == 0 ? cls : x[r]) + pos[r % L]
 hipError_t launch_layernorm_f32(const float* x, const float* w, const float* b, float* out, int M, int D,
-                                hipStream_t s);
+                                hipStream_t s, const float* pos = nullptr, const float* cls = nullptr, int L = 1);
 // NCHW fp32 crops -> patch matrix fp16 [B*g*g, 3*p*p] (token t = g*row+col, k = c*p*p+ky*p+kx).
 hipError_t launch_im2col(const float* x, half_t* out, int B, int R, int p, hipStream_t s);
-// x[b*L + 0][:] = cls + pos[0]
-hipError_t launch_cls_rows(float* x, const float* cls, const float* pos, int B, int L, int D, hipStream_t s);
 // x[r][:] = table[ids[r/L*ld_ids + r%L]][:] + pos[r%L][:]   (text: token_embedding + positional)
 hipError_t launch_embed_tokens(const int32_t* ids, int ld_ids, const float* table, const float* pos, float* x,
                                int T, int L, int D, int vocab, hipStream_t s);
@@ -141,7 +140,8 @@ hipError_t launch_rowstats_cast(const float* x, half_t* x16, float* mr, float* m
                                 float* muc = nullptr);   // muc (optional): centre of the copy as well (= mu)
 // x = LayerNorm(x; w, b) in place (fp32) followed by rowstats_cast of the result, in one pass (ln_pre of the vision tower)
 hipError_t launch_layernorm_rowstats(float* x, const float* w, const float* b, half_t* x16, float* mr, float* mu, float* muc,
-                                     int M, int D, hipStream_t s);
+                                     int M, int D, hipStream_t s, const float* pos = nullptr, const float* cls = nullptr,
+                                     int L = 1);
 // stats [M][nt][2]: per column group of gw columns (sum, sum of squared deviations from the group mean)
 // -> mr [M][2] = (mean - mu[m], rstd) over the nt * gw columns, eps 1e-5, then mu[m] = mean (the centre the next
 // residual GEMM subtracts from its fp16 copy)
