@@ -49,6 +49,7 @@ KIND_NAMES = {0: "gemm bias->f16", 1: "gemm bias+QuickGELU->f16", 2: "gemm bias+
               8: "gemm_ring<LN-fold bias->f16>", 9: "gemm_ring<LN-fold bias+QuickGELU->f16>",
               10: "gemm_ring2<residual + x16 + row stats>", 11: "gemm adapter down_proj", 12: "gemm_duo<adapter up_proj>",
               13: "gemm_ring<VAE mean|log_var + reparameterise>", 100: "attention_kernel"}
+    14: "gemm_duo<adapter up_proj, fp16 copy only>",
 
 
 # ----------------------------------------------------------------------------------------------------------------

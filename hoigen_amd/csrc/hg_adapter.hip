@@ -80,7 +80,7 @@ struct DecoderPtrs {
 __global__ __launch_bounds__(64) void adapter_decoder_kernel(const float* __restrict__ down, int ld_down,
                                                              DecoderPtrs P, const float* __restrict__ kv,
                                                              const uint8_t* __restrict__ mask, int L, int Nmem,
-                                                             int chunks, half_t* __restrict__ out16) {
+                                                             int chunks, half_t* __restrict__ out16, int ld16) {
     __shared__ float rows[64][ROWP];
     const int lane = threadIdx.x;
     const int seq = blockIdx.x / chunks, ch = blockIdx.x - seq * chunks;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64) void adapter_decoder_kernel(const float* __rest
     }
     layer_norm64(tgt, P.norms + 2 * AD, P.norms + 3 * AD);
     if (valid) {
-        half_t* dst = out16 + m * AD;
+        half_t* dst = out16 + (size_t)m * ld16;
 #pragma unroll
         for (int o = 0; o < AD; o += 8) {
             half8 h;
@@ -288,7 +288,7 @@ template <bool SELF>
 // `down` is not __restrict__: a chained layer (adapter_num_layers > 1) writes chain32 == down in place
 __global__ __launch_bounds__(256) void adapter_decoder_mfma(const float* down, int ld_down, DecW16 W,
                                                             const float* __restrict__ priors, const uint8_t* __restrict__ mask,
-                                                            int L, int N, half_t* __restrict__ out16, float* chain32) {
+                                                            int L, int N, half_t* __restrict__ out16, float* chain32, int ld16) {
     extern __shared__ __attribute__((aligned(16))) char smem_ad[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256) void adapter_decoder_mfma(const float* down, i
 #pragma unroll
     for (int f = 0; f < 4; ++f)
         if (tok[f] < L) {
-            half_t* dst = out16 + ((size_t)seq * L + tok[f]) * AD;
+            half_t* dst = out16 + ((size_t)seq * L + tok[f]) * ld16;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 half4 h;
@@ -487,7 +487,8 @@ __global__ __launch_bounds__(256) void adapter_decoder_mfma(const float* down, i
 // down32 [M,128] fp32 (cols 0..63 = relu(down_proj(x))) -> out16 [M,64] fp16 = decoder layer output
 hipError_t launch_adapter_decoder(const float* down32, const AdapterDev& ad, const float* priors,
                                   const uint8_t* mask, int B, int L, int N, float* kv, half_t* out16,
-                                  hipStream_t s, float* chain32) {
+                                  hipStream_t s, float* chain32, int ld16) {
+    if (ld16 < AD || ld16 % 8) return hipErrorInvalidValue;
     const int which = priors ? 0 : 1;            // mhsa_layers.0 (prior) vs mhsa (self)
     const float* const* dl = ad.dl[which];
     const int Nmem = priors ? N : L;
@@ -510,9 +511,9 @@ hipError_t launch_adapter_decoder(const float* down32, const AdapterDev& ad, con
             attr_set = true;
         }
         if (priors)
-            hipLaunchKernelGGL((adapter_decoder_mfma<false>), dim3(B), dim3(256), lds, s, down32, 128, Wd, priors, mask, L, N, out16, chain32);
+            hipLaunchKernelGGL((adapter_decoder_mfma<false>), dim3(B), dim3(256), lds, s, down32, 128, Wd, priors, mask, L, N, out16, chain32, ld16);
         else
-            hipLaunchKernelGGL((adapter_decoder_mfma<true>), dim3(B), dim3(256), lds, s, down32, 128, Wd, priors, mask, L, L, out16, chain32);
+            hipLaunchKernelGGL((adapter_decoder_mfma<true>), dim3(B), dim3(256), lds, s, down32, 128, Wd, priors, mask, L, L, out16, chain32, ld16);
         return hipGetLastError();
     }
     if (chain32) return hipErrorInvalidValue;      // chained layers exist only on the MFMA path
@@ -521,7 +522,7 @@ hipError_t launch_adapter_decoder(const float* down32, const AdapterDev& ad, con
     DecoderPtrs P{dl[0], dl[3], dl[6], dl[7], dl[8], dl[9], dl[10], dl[11]};
     const int chunks = (L + 63) / 64;
     hipLaunchKernelGGL(adapter_decoder_kernel, dim3(B * chunks), dim3(64), 0, s, down32, 128, P, kv,
-                       priors ? mask : (const uint8_t*)nullptr, L, Nmem, chunks, out16);
+                       priors ? mask : (const uint8_t*)nullptr, L, Nmem, chunks, out16, ld16);
     return hipGetLastError();
 }
 

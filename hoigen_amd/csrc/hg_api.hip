@@ -48,6 +48,9 @@ struct AdapterW {
     half_t* up_w = nullptr;    // [D, 64]
     float* up_b = nullptr;
     float* scale = nullptr;
+    // K-concatenated out-proj of the block this adapter sits in: [W_out | scale * W_up] ([D, D + 64]) and b_out + scale * b_up
+    half_t* wk_out = nullptr;
+    float* bk_out = nullptr;
     float* dl[2][12] = {};     // see AdapterDev
     half_t* w16[2][6] = {};    // see AdapterDev
     struct Extra { float* dl[12] = {}; half_t* w16[6] = {}; };
@@ -434,6 +437,12 @@ int load_adapters(hg_ctx* c, const hg_adapter_weights* src, int layers) {
             rc = load_decoder_layer(c, own, s.extra_prior_layers[z], d, a.extra[z].dl, a.extra[z].w16);
             if (rc) return rc;
         }
+        if ((int)v.blocks.size() > i && v.blocks[i].w_out) {
+            keep_first(rc, dev_alloc(c, own, (size_t)D * (D + d) * 2, (void**)&a.wk_out));
+            keep_first(rc, dev_alloc(c, own, (size_t)D * 4, (void**)&a.bk_out));
+            if (rc) return rc;
+            HG_HIP(launch_concat_upproj(v.blocks[i].w_out, v.blocks[i].b_out, a.up_w, a.up_b, a.scale, a.wk_out, a.bk_out, D, D, d, 0));
+        }
         a.present = true;
     }
     HG_HIP(hipDeviceSynchronize());
@@ -466,9 +475,10 @@ hipError_t gemm(hg_ctx* c, int epi, const GemmArgs& g, hipStream_t s) {
     return launch_gemm(epi, g, s);
 }
 
-hipError_t attention(hg_ctx* c, const half_t* qkv, half_t* out, int n_seq, int L, int heads, bool causal, hipStream_t s) {
+hipError_t attention(hg_ctx* c, const half_t* qkv, half_t* out, int n_seq, int L, int heads, bool causal, hipStream_t s,
+                     int ldo = 0) {
     ProfScope ps(c, s, HG_PROF_ATTENTION, n_seq, L, heads);
-    return launch_attention(qkv, out, n_seq, L, heads, causal, s);
+    return launch_attention(qkv, out, n_seq, L, heads, causal, s, ldo);
 }
 
 // ---- one transformer tower over the residual stream in c->x ------------------------------------------
@@ -481,7 +491,11 @@ struct AdapterCall {
 
 // `fused`: LayerNorm folding is on - the stream's centred fp16 copy (c->h), its centre (c->muc) and the folding
 // statistics are current; the adapter consumes the copy and its up_proj re-emits all three for the updated stream
-int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const AdapterCall& ac, hipStream_t s, bool fused);
+// `kcat`: the adapter's update of the fp32 stream is left to the block's K-concatenated out-proj ([att | d] x [W_out | scale W_up]):
+// the decoder output d goes into columns D .. D+63 of the attention output buffer (row stride D + 64) and up_proj only refreshes
+// the centred fp16 copy + statistics that ln_1 needs (EPI_X16_SCALE_LN: no fp32 traffic at all)
+int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const AdapterCall& ac, hipStream_t s, bool fused,
+                bool kcat = false);
 
 // LayerNorm folded into the GEMMs: the residual GEMMs (out-proj, c_proj) also emit the fp16 copy of the updated
 // rows and per-row partial statistics; the consuming GEMMs (QKV, c_fc) read that copy and apply mean / rstd in
@@ -567,8 +581,18 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
     if (pre_w && trace) HG_HIP(launch_copy_rows(x, trace, n_seq, L, D, s));
     for (size_t i = 0; i < blocks.size(); ++i) {
         const BlockW& b = blocks[i];
+        // HG_ADAPTER_KCAT=0: the adapter's up_proj updates the fp32 stream itself (EPI_SCALE_RESID_LN_F32)
+        static const bool kcat_on = []() { const char* e = getenv("HG_ADAPTER_KCAT"); return !(e && e[0] == '0'); }();
+        bool kcat = false;
         if (adapters && c->vit.adapters.size() > i && c->vit.adapters[i].present) {
-            int rc = run_adapter(c, c->vit.adapters[i], n_seq, L, D, *ac, s, fuse);
+            const AdapterW& aw = c->vit.adapters[i];
+            kcat = fuse && kcat_on && aw.wk_out && !(row0_out && row0_env && i + 1 == blocks.size());
+            if (kcat) {
+                int rc = ensure(c, c->att, rup(M, 256) * (size_t)(D + 64) * 2);
+                if (rc) return rc;
+                att = (half_t*)c->att.p;
+            }
+            int rc = run_adapter(c, aw, n_seq, L, D, *ac, s, fuse, kcat);
             if (rc) return rc;
         }
         const bool row0_last = row0_out && row0_env && !adapters && i + 1 == blocks.size();
@@ -615,9 +639,12 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
             *row0_out = cx;
             break;
         }
-        HG_HIP(attention(c, qkv, att, n_seq, L, heads, causal, s));
+        HG_HIP(attention(c, qkv, att, n_seq, L, heads, causal, s, kcat ? D + 64 : 0));
         g = GemmArgs{};
         g.A = att; g.lda = D; g.W = b.w_out; g.bias = b.b_out; g.out = x; g.ldc = D; g.M = M; g.N = D; g.K = D;
+        if (kcat) {      // x += [att | d] [W_out | scale W_up]^T + (b_out + scale b_up): the adapter's update rides along
+            g.lda = D + 64; g.K = D + 64; g.W = c->vit.adapters[i].wk_out; g.bias = c->vit.adapters[i].bk_out;
+        }
         if (fuse) {
             g.out2 = h; g.stats = stats; g.stats_ld = sld; g.mu = mu;
             HG_HIP(gemm(c, EPI_RESID_LN_F32, g, s));
@@ -660,7 +687,8 @@ int ensure_tower_ws(hg_ctx* c, int M, int D) {
     return rc;
 }
 
-int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const AdapterCall& ac, hipStream_t s, bool fused) {
+int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const AdapterCall& ac, hipStream_t s, bool fused,
+                bool kcat) {
     const int M = n_seq * L;
     float* x = (float*)c->x.p;
     half_t* h = (half_t*)c->h.p;
@@ -702,9 +730,10 @@ int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const Ada
             for (int j = 0; j < 12; ++j) ad.dl[0][j] = a.extra[z - 1].dl[j];
         if (z > 0)
             for (int j = 0; j < 6; ++j) ad.w16[0][j] = a.extra[z - 1].w16[j];
+        half_t* d16 = kcat ? (half_t*)c->att.p + D : (half_t*)c->ad16.p;
         hipError_t e = launch_adapter_decoder((const float*)c->ad32.p, ad, ac.priors, ac.mask, n_seq, L, ac.priors ? ac.N : 0,
-                                              (float*)c->adkv.p, (half_t*)c->ad16.p, s,
-                                              z + 1 < n_chain ? (float*)c->ad32.p : nullptr);
+                                              (float*)c->adkv.p, d16, s,
+                                              z + 1 < n_chain ? (float*)c->ad32.p : nullptr, kcat ? D + 64 : 64);
         if (e != hipSuccess)
             return fail(c, HG_ERR_HIP, "adapter decoder layer %d failed: %s", z, hipGetErrorString(e));
     }
@@ -712,7 +741,14 @@ int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const Ada
     g = GemmArgs{};
     g.A = (const half_t*)c->ad16.p; g.lda = 64; g.W = a.up_w; g.bias = a.up_b; g.pos = a.scale; g.out = x; g.ldc = D;
     g.M = M; g.N = D; g.K = 64;
-    if (fused) {       // ... and re-emit the fp16 copy + row statistics of the updated stream for the folded ln_1
+    if (fused && kcat) {   // the stream gets the update in out-proj; ln_1 needs the fp16 copy + statistics of x + a now
+        const int sld = 4 * (D / 256);
+        g.A = (const half_t*)c->att.p + D; g.lda = D + 64; g.out = nullptr;
+        g.out2 = h; g.stats = (float*)c->stats.p; g.stats_ld = sld;
+        HG_HIP(gemm(c, EPI_X16_SCALE_LN, g, s));
+        HG_HIP(launch_finalize_stats((const float*)c->stats.p, (float*)c->mr.p, (float*)c->mu.p, M, sld, 64, s,
+                                     (float*)c->muc.p, true));
+    } else if (fused) {       // ... and re-emit the fp16 copy + row statistics of the updated stream for the folded ln_1
         const int sld = 4 * (D / 256);
         g.out2 = h; g.stats = (float*)c->stats.p; g.stats_ld = sld; g.mu = (const float*)c->mu.p;
         HG_HIP(gemm(c, EPI_SCALE_RESID_LN_F32, g, s));

@@ -122,7 +122,7 @@ __device__ __forceinline__ void tile_softmax_pv(const char* vb, const int (&v_of
 template <bool CAUSAL, bool ROW0>
 __global__ __launch_bounds__(448) void attention_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
                                                         int L, int heads, int nkt, const half_t* __restrict__ q0,
-                                                        const int32_t* __restrict__ sel, const int mode) {
+                                                        const int32_t* __restrict__ sel, const int mode, const int ldo) {
     // timing-experiment switches (HG_ATTN_MODE bits 1 no key loop, 2 no K/V staging, 4 no stores, 8 no Q loads; wrong results) exist
     // only in a -DHG_EXPERIMENTS build
 #ifdef HG_EXPERIMENTS
@@ -241,14 +241,15 @@ __global__ __launch_bounds__(448) void attention_kernel(const half_t* __restrict
             const int row = rb + cr, qq = qt * 32 + row;
             const half8 v = *reinterpret_cast<const half8*>(ot + row * 128 + ((cc ^ (row & 7)) << 4));
             if (qq < L && !(xmode & 4))
-                *reinterpret_cast<half8*>(out + ((size_t)seq * L + qq) * D + head * HD + cc * 8) = v;
+                *reinterpret_cast<half8*>(out + ((size_t)seq * L + qq) * ldo + head * HD + cc * 8) = v;
         }
     }
 }
 
 template <bool CAUSAL, bool ROW0 = false>
 static hipError_t launch_t(const half_t* qkv, half_t* out, int n_seq, int L, int heads, hipStream_t s,
-                           const half_t* q0 = nullptr, const int32_t* sel = nullptr) {
+                           const half_t* q0 = nullptr, const int32_t* sel = nullptr, int ldo = 0) {
+    if (ldo <= 0) ldo = heads * HD;
     const int nkt = (L + 31) / 32;
     const int lds = 2 * ((L + 15) & ~15) * ROWB;
     static bool attr_set_d[HG_MAX_DEVICES] = {};      // function attributes are per device
@@ -261,15 +262,16 @@ static hipError_t launch_t(const half_t* qkv, half_t* out, int n_seq, int L, int
     }
     static const int mode = getenv("HG_ATTN_MODE") ? atoi(getenv("HG_ATTN_MODE")) : 0;   // read by experiment builds only
     hipLaunchKernelGGL((attention_kernel<CAUSAL, ROW0>), dim3(n_seq * heads), dim3(64 * nkt), lds, s, qkv, out, L, heads, nkt, q0, sel,
-                       mode);
+                       mode, ldo);
     return hipGetLastError();
 }
 
 hipError_t launch_attention(const half_t* qkv, half_t* out, int n_seq, int L, int heads, bool causal,
-                            hipStream_t s) {
+                            hipStream_t s, int ldo) {
     if (n_seq <= 0) return hipSuccess;
-    if (L < 1 || L > 224) return hipErrorInvalidValue;
-    return causal ? launch_t<true>(qkv, out, n_seq, L, heads, s) : launch_t<false>(qkv, out, n_seq, L, heads, s);
+    if (L < 1 || L > 224 || (ldo != 0 && (ldo < heads * HD || ldo % 8))) return hipErrorInvalidValue;
+    return causal ? launch_t<true>(qkv, out, n_seq, L, heads, s, nullptr, nullptr, ldo)
+                  : launch_t<false>(qkv, out, n_seq, L, heads, s, nullptr, nullptr, ldo);
 }
 
 hipError_t launch_attention_row0(const half_t* qkv, const half_t* q0, const int32_t* sel, half_t* out, int n_seq, int L,

@@ -649,7 +649,7 @@ hipError_t launch_rowstats_cast(const float* x, half_t* x16, float* mr, float* m
 // partial statistics of row m over nt column groups of `gw` columns each: (sum_k, M2_k = sum (x - mean_k)^2);
 // combined with Chan's parallel-variance formula (no E[x^2] - mean^2 cancellation)
 __global__ void finalize_stats_kernel(const float* __restrict__ stats, float* __restrict__ mr, float* __restrict__ mu,
-                                      int M, int nt, int gw, float* __restrict__ muc) {
+                                      int M, int nt, int gw, float* __restrict__ muc, int centred) {
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
     const float* sp = stats + (size_t)m * nt * 2;
@@ -663,14 +663,34 @@ __global__ void finalize_stats_kernel(const float* __restrict__ stats, float* __
         m2 += sp[2 * t + 1] + (float)gw * d * d;
     }
     const float c = mu[m];
-    mr[2 * (size_t)m] = mean - c;                 // the fp16 copy of this row was written as x - mu[m]
+    mr[2 * (size_t)m] = centred ? mean : mean - c;   // the fp16 copy of this row was written as x - mu[m]
     mr[2 * (size_t)m + 1] = 1.0f / sqrtf(m2 / D + 1e-5f);
     if (muc) muc[m] = c;                          // centre of the current copy (adapter down_proj adds it back)
-    mu[m] = mean;                                 // centre for the next residual GEMM's copy
+    if (!centred) mu[m] = mean;                   // centre for the next residual GEMM's copy
 }
-hipError_t launch_finalize_stats(const float* stats, float* mr, float* mu, int M, int nt, int gw, hipStream_t s, float* muc) {
+hipError_t launch_finalize_stats(const float* stats, float* mr, float* mu, int M, int nt, int gw, hipStream_t s, float* muc,
+                                 bool centred) {
     if (M <= 0) return hipSuccess;
-    hipLaunchKernelGGL(finalize_stats_kernel, dim3((M + 255) / 256), dim3(256), 0, s, stats, mr, mu, M, nt, gw, muc);
+    hipLaunchKernelGGL(finalize_stats_kernel, dim3((M + 255) / 256), dim3(256), 0, s, stats, mr, mu, M, nt, gw, muc,
+                       centred ? 1 : 0);
+    return hipGetLastError();
+}
+
+// [w_out | fp16(scale * up_w)] and b_out + scale * up_b (weight-load time)
+__global__ __launch_bounds__(256) void concat_upproj_kernel(const half_t* __restrict__ w_out, const float* __restrict__ b_out,
+                                                            const half_t* __restrict__ up_w, const float* __restrict__ up_b,
+                                                            const float* __restrict__ scale, half_t* __restrict__ wk,
+                                                            float* __restrict__ bk, int N, int K, int d) {
+    const int n = blockIdx.x;
+    const float sc = scale[n];
+    for (int k = threadIdx.x; k < K + d; k += 256)
+        wk[(size_t)n * (K + d) + k] = k < K ? w_out[(size_t)n * K + k] : (half_t)(sc * (float)up_w[(size_t)n * d + (k - K)]);
+    if (threadIdx.x == 0) bk[n] = b_out[n] + sc * up_b[n];
+}
+hipError_t launch_concat_upproj(const half_t* w_out, const float* b_out, const half_t* up_w, const float* up_b,
+                                const float* scale, half_t* wk, float* bk, int N, int K, int d, hipStream_t s) {
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(concat_upproj_kernel, dim3(N), dim3(256), 0, s, w_out, b_out, up_w, up_b, scale, wk, bk, N, K, d);
     return hipGetLastError();
 }
 

@@ -222,7 +222,8 @@ hipError_t launch_gemm(int epi, const GemmArgs& a, hipStream_t s) {
     // two-workgroups-per-CU kernel (117 / 293 us against 147 / 305 us of the ring kernels at M = 50432); 2 = every
     // epilogue it implements except the LayerNorm-emitting residual (ring2 and duo tie there); 3 = that one as well
     static const int duo = []() { const char* e = getenv("HG_DUO"); return e ? atoi(e) : 1; }();
-    if (epi == EPI_SCALE_RESID_LN_F32) return gemm_duo_ok(epi, a) ? launch_gemm_duo(epi, a, s) : hipErrorInvalidValue;
+    if (epi == EPI_SCALE_RESID_LN_F32 || epi == EPI_X16_SCALE_LN)
+        return gemm_duo_ok(epi, a) ? launch_gemm_duo(epi, a, s) : hipErrorInvalidValue;
     if (epi == EPI_MU_BIAS_RELU_F32) return launch_gemm_simple(epi, a, s);
     const bool use_duo = duo >= 3 || (duo == 2 && epi != EPI_RESID_LN_F32) || (duo == 1 && epi == EPI_BIAS_RESID_F32);
     if (!force_simple && use_duo && gemm_duo_ok(epi, a)) return launch_gemm_duo(epi, a, s);

@@ -35,7 +35,11 @@ enum Epilogue : int {
     // interleaved in blocks of 128 (tile column block 0 = mean columns j, block 1 = log_var columns j), so one lane holds
     // mean_j and log_var_j of a row:  mean = out[m][j], log_var = out_hi[m][j], z = exp(0.5 log_var) * eps + mean with
     // eps = pos[m][j] -> out3 (fp32, nullable) and out2 (fp16, the generator's operand); ring kernels only
-    EPI_VAE_REPARAM_F32 = 13
+    EPI_VAE_REPARAM_F32 = 13,
+    // adapter up_proj without touching the fp32 stream (variant C, K-concatenated out-proj): the centred fp16 copy out2 is
+    // updated IN PLACE, out2 = fp16(out2 + (acc + bias) * pos[n]), and the statistics of the updated (centred) values are
+    // emitted; the stream itself receives the same update inside the out-proj GEMM ([att | d] x [W_out | scale W_up]); duo only
+    EPI_X16_SCALE_LN = 14
 };
 
 struct GemmArgs {
@@ -82,8 +86,9 @@ hipError_t launch_gemm_duo(int epi, const GemmArgs& a, hipStream_t s);
 // ---- attention: softmax(Q K^T / sqrt(64) [+causal]) V, head_dim 64 --------------------------
 // qkv fp16 [n_seq*L, 3*D] rows = tokens (q|k|v column blocks, head h = 64h..64h+63);
 // out fp16 [n_seq*L, D].  L <= 224.
+// ldo: row stride of out in halfs (0 = heads * 64)
 hipError_t launch_attention(const half_t* qkv, half_t* out, int n_seq, int L, int heads, bool causal,
-                            hipStream_t s);
+                            hipStream_t s, int ldo = 0);
 // attention of ONE query row per sequence (row sel[seq], row 0 when sel is null; sel[seq] < L): K and V from
 // qkv [n_seq*L, 3*heads*64], the queries from q0 [n_seq, heads*64] (dense), out [n_seq, heads*64] (dense)
 hipError_t launch_attention_row0(const half_t* qkv, const half_t* q0, const int32_t* sel, half_t* out, int n_seq, int L,
@@ -146,8 +151,13 @@ hipError_t launch_layernorm_rowstats(float* x, const float* w, const float* b, h
 // -> mr [M][2] = (mean - mu[m], rstd) over the nt * gw columns, eps 1e-5, then mu[m] = mean (the centre the next
 // residual GEMM subtracts from its fp16 copy)
 // muc (optional) receives the centre the CURRENT fp16 copy was written with (mu before this call)
+// centred: the statistics are those of ALREADY CENTRED values (EPI_X16_SCALE_LN): mr = (mean, rstd), mu stays
 hipError_t launch_finalize_stats(const float* stats, float* mr, float* mu, int M, int nt, int gw, hipStream_t s,
-                                 float* muc = nullptr);
+                                 float* muc = nullptr, bool centred = false);
+// K-concatenated out-proj operand of a block with an adapter: wk [N, K + d] = [w_out | fp16(scale[n] * up_w[n][:])],
+// bk [N] = b_out + scale * up_b
+hipError_t launch_concat_upproj(const half_t* w_out, const float* b_out, const half_t* up_w, const float* up_b,
+                                const float* scale, half_t* wk, float* bk, int N, int K, int d, hipStream_t s);
 
 #define HG_PRE_HDR 24   // header words per box in the pre-processing table (layout: hg_preproc.hip)
 // ---- crop pre-processing (hg_preproc.hip): head = per-box headers written by the host, tab receives the weight
@@ -181,8 +191,10 @@ struct AdapterDev {      // device pointers, all fp32 except the two MFMA operan
 // kv: scratch [B*Nmem, 2, 64] fp32 with Nmem = N (prior given) or L (prior == nullptr).
 // chain32 (optional, adapter_num_layers > 1): write the layer's output as fp32 into this [M,128] buffer (may be down32
 // itself) instead of out16, for the next decoder layer of the chain
+// ld16: row stride of out16 in halfs (64 = dense; D + 64 when the rows are the right-hand columns of the K-concatenated
+// out-proj operand [att | d])
 hipError_t launch_adapter_decoder(const float* down32, const AdapterDev& ad, const float* priors,
                                   const uint8_t* mask, int B, int L, int N, float* kv, half_t* out16,
-                                  hipStream_t s, float* chain32 = nullptr);
+                                  hipStream_t s, float* chain32 = nullptr, int ld16 = 64);
 
 }  // namespace hg
