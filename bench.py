@@ -48,8 +48,8 @@ KIND_NAMES = {0: "gemm bias->f16", 1: "gemm bias+QuickGELU->f16", 2: "gemm bias+
               4: "gemm bias->f32", 5: "gemm patch-embed", 6: "gemm bias+ReLU->f32", 7: "gemm scale+residual",
               8: "gemm_ring<LN-fold bias->f16>", 9: "gemm_ring<LN-fold bias+QuickGELU->f16>",
               10: "gemm_ring2<residual + x16 + row stats>", 11: "gemm adapter down_proj", 12: "gemm_duo<adapter up_proj>",
-              13: "gemm_ring<VAE mean|log_var + reparameterise>", 100: "attention_kernel"}
-    14: "gemm_duo<adapter up_proj, fp16 copy only>",
+              13: "gemm_ring<VAE mean|log_var + reparameterise>", 14: "gemm_duo<adapter up_proj, fp16 copy only>",
+              100: "attention_kernel"}
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -250,7 +250,8 @@ __device__ __forceinline__ void store_T(const f32x4 (&t)[4][G], half_t* X, int l
             *reinterpret_cast<half4*>(X + (16 * f + r) * XP + 16 * g + 4 * q) = h;
         }
 }
-// LayerNorm over the 64 features of every token (eps 1e-5, biased variance), in place
+// LayerNorm over the 64 features of every token (eps 1e-5, biased variance), in place; AFFINE = false: normalised values only
+template <bool AFFINE = true>
 __device__ __forceinline__ void layer_norm_T(f32x4 (&t)[4][4], const float* __restrict__ w, const float* __restrict__ b, int lane) {
     const int q = lane >> 4;
 #pragma unroll
@@ -270,9 +271,14 @@ __device__ __forceinline__ void layer_norm_T(f32x4 (&t)[4][4], const float* __re
         const float rstd = 1.0f / sqrtf(sum_rows4(v) * (1.0f / 64.0f) + 1e-5f);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + 16 * g + 4 * q), bv = *reinterpret_cast<const f32x4*>(b + 16 * g + 4 * q);
+            if constexpr (AFFINE) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w + 16 * g + 4 * q), bv = *reinterpret_cast<const f32x4*>(b + 16 * g + 4 * q);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) t[f][g][e] = (t[f][g][e] - mean) * rstd * wv[e] + bv[e];
+                for (int e = 0; e < 4; ++e) t[f][g][e] = (t[f][g][e] - mean) * rstd * wv[e] + bv[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[f][g][e] = (t[f][g][e] - mean) * rstd;
+            }
         }
     }
 }
@@ -288,7 +294,8 @@ template <bool SELF>
 // `down` is not __restrict__: a chained layer (adapter_num_layers > 1) writes chain32 == down in place
 __global__ __launch_bounds__(256) void adapter_decoder_mfma(const float* down, int ld_down, DecW16 W,
                                                             const float* __restrict__ priors, const uint8_t* __restrict__ mask,
-                                                            int L, int N, half_t* __restrict__ out16, float* chain32, int ld16) {
+                                                            int L, int N, half_t* __restrict__ out16, float* chain32, int ld16,
+                                                            AdapterFoldDev F) {
     extern __shared__ __attribute__((aligned(16))) char smem_ad[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -459,7 +466,57 @@ __global__ __launch_bounds__(256) void adapter_decoder_mfma(const float* down, i
     for (int f = 0; f < 4; ++f)
 #pragma unroll
         for (int g = 0; g < 4; ++g) tgt[f][g] += t[f][g];
-    layer_norm_T(tgt, W.norms + 128, W.norms + 192, lane);
+    if (F.mr) {
+        // Folded adapter (hg_elem.hip adapter_q_kernel): the layer hands on e = [z_0 .. z_62, 1] (z = norm3 without its affine
+        // part) - the block's QKV and out-proj GEMMs take the update a = Q e as 64 more K columns - and the statistics ln_1
+        // needs of y = x + a, from those of x and three 64-wide products:
+        //   sum_j a_j = e . qm,   sum_j (x_j - c) a_j = e . w'  (w' = x16 Q: columns 64.. of the down_proj GEMM),   sum_j a_j^2 = e^T G e
+        layer_norm_T<false>(tgt, nullptr, nullptr, lane);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            if (q == 3) tgt[f][3][3] = 1.0f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tgt[f][g][e] = (float)(half_t)tgt[f][g][e];      // as the GEMMs will read it
+        }
+        store_T<4>(tgt, Xw, lane);
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) t[f][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        linear_T<4, 2>(t, F.g16, 64, Xw, lane);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const size_t m = (size_t)seq * L + (tok[f] < L ? tok[f] : L - 1);
+            float sa = 0.f, cr = 0.f, qd = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 qmv = *reinterpret_cast<const f32x4*>(F.qm + 16 * g + 4 * q);
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(down + m * ld_down + 64 + 16 * g + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sa = fmaf(tgt[f][g][e], qmv[e], sa);
+                    cr = fmaf(tgt[f][g][e], wv[e], cr);
+                    qd = fmaf(tgt[f][g][e], t[f][g][e], qd);
+                }
+            }
+            sa = sum_rows4(sa);
+            cr = sum_rows4(cr);
+            qd = sum_rows4(qd);
+            if (q == 0 && tok[f] < L) {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                f32x2* mrp = reinterpret_cast<f32x2*>(F.mr + 2 * m);
+                const f32x2 old = *mrp;                          // (mean_x - c, rstd_x)
+                const float var_x = 1.0f / (old[1] * old[1]) - 1e-5f;
+                const float dv = (2.0f * (cr - old[0] * sa) + (qd - sa * sa * F.inv_D)) * F.inv_D;
+                const float var_y = fmaxf(var_x + dv, 0.f);
+                *mrp = f32x2{old[0] + sa * F.inv_D, 1.0f / sqrtf(var_y + 1e-5f)};
+            }
+        }
+    } else {
+        layer_norm_T(tgt, W.norms + 128, W.norms + 192, lane);
+    }
     if (chain32) {      // adapter_num_layers > 1: fp32, in the layout the next layer of the chain reads (rows of ld_down)
 #pragma unroll
         for (int f = 0; f < 4; ++f)
@@ -484,18 +541,27 @@ __global__ __launch_bounds__(256) void adapter_decoder_mfma(const float* down, i
         }
 }
 
+static bool decoder_mfma_on() {
+    static const bool on = []() { const char* e = getenv("HG_ADAPTER_MFMA"); return !(e && e[0] == '0'); }();
+    return on;
+}
+bool adapter_decoder_mfma_ok(const AdapterDev& ad, bool priors, int L, int N) {
+    return decoder_mfma_on() && ad.w16[priors ? 0 : 1][0] && L <= NKMAX && (priors ? N <= 32 : true);
+}
+
 // down32 [M,128] fp32 (cols 0..63 = relu(down_proj(x))) -> out16 [M,64] fp16 = decoder layer output
 hipError_t launch_adapter_decoder(const float* down32, const AdapterDev& ad, const float* priors,
                                   const uint8_t* mask, int B, int L, int N, float* kv, half_t* out16,
-                                  hipStream_t s, float* chain32, int ld16) {
+                                  hipStream_t s, float* chain32, int ld16, const AdapterFoldDev* fold) {
     if (ld16 < AD || ld16 % 8) return hipErrorInvalidValue;
+    AdapterFoldDev F{};
+    if (fold && !chain32) F = *fold;
     const int which = priors ? 0 : 1;            // mhsa_layers.0 (prior) vs mhsa (self)
     const float* const* dl = ad.dl[which];
     const int Nmem = priors ? N : L;
     const int n_rows = B * Nmem;
     if (n_rows <= 0) return hipSuccess;
-    static const bool mfma_on = []() { const char* e = getenv("HG_ADAPTER_MFMA"); return !(e && e[0] == '0'); }();
-    if (mfma_on && ad.w16[which][0] && L <= NKMAX && (priors ? N <= 32 : true)) {
+    if (adapter_decoder_mfma_ok(ad, priors != nullptr, L, N)) {
         const half_t* const* w = ad.w16[which];
         DecW16 Wd{w[0], w[1], w[2], w[3], w[4], w[5], dl[3], dl[4], dl[5], dl[7], dl[10], dl[11] + (size_t)2 * AD * AD, dl[8]};
         const int lds = (4 * 64 * XP + NKMAX * KP + 64 * VP + 64 * XP) * 2;
@@ -511,12 +577,12 @@ hipError_t launch_adapter_decoder(const float* down32, const AdapterDev& ad, con
             attr_set = true;
         }
         if (priors)
-            hipLaunchKernelGGL((adapter_decoder_mfma<false>), dim3(B), dim3(256), lds, s, down32, 128, Wd, priors, mask, L, N, out16, chain32, ld16);
+            hipLaunchKernelGGL((adapter_decoder_mfma<false>), dim3(B), dim3(256), lds, s, down32, 128, Wd, priors, mask, L, N, out16, chain32, ld16, F);
         else
-            hipLaunchKernelGGL((adapter_decoder_mfma<true>), dim3(B), dim3(256), lds, s, down32, 128, Wd, priors, mask, L, L, out16, chain32, ld16);
+            hipLaunchKernelGGL((adapter_decoder_mfma<true>), dim3(B), dim3(256), lds, s, down32, 128, Wd, priors, mask, L, L, out16, chain32, ld16, F);
         return hipGetLastError();
     }
-    if (chain32) return hipErrorInvalidValue;      // chained layers exist only on the MFMA path
+    if (chain32 || F.mr) return hipErrorInvalidValue;      // chained layers and the folded statistics exist only on the MFMA path
     hipLaunchKernelGGL(adapter_kv_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, s, priors ? priors : down32,
                        priors ? AD : 128, n_rows, dl[1], dl[4], dl[2], dl[5], kv);
     DecoderPtrs P{dl[0], dl[3], dl[6], dl[7], dl[8], dl[9], dl[10], dl[11]};

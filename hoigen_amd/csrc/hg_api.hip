@@ -51,6 +51,15 @@ struct AdapterW {
     // K-concatenated out-proj of the block this adapter sits in: [W_out | scale * W_up] ([D, D + 64]) and b_out + scale * b_up
     half_t* wk_out = nullptr;
     float* bk_out = nullptr;
+    // The adapter folded into the block's GEMMs altogether (hg_elem.hip adapter_q_kernel): a = Q e with e = the last decoder
+    // layer's normalised output; [0] = prior path (last layer of the mhsa_layers chain), [1] = self path (mhsa)
+    struct Fold {
+        half_t* down2 = nullptr;    // [128, D]: down_proj rows | Q^T (the cross term of the statistics rides in the padded half)
+        half_t* wk_out = nullptr;   // [D, D + 64] = [W_out | Q]
+        half_t* wq_cat = nullptr;   // [3D, D + 64] = [W'_qkv | W'_qkv Q]
+        half_t* g16 = nullptr;      // [64, 64] Q^T Q
+        float* qm = nullptr;        // [64] column sums of Q
+    } fold[2];
     float* dl[2][12] = {};     // see AdapterDev
     half_t* w16[2][6] = {};    // see AdapterDev
     struct Extra { float* dl[12] = {}; half_t* w16[6] = {}; };
@@ -443,6 +452,27 @@ int load_adapters(hg_ctx* c, const hg_adapter_weights* src, int layers) {
             if (rc) return rc;
             HG_HIP(launch_concat_upproj(v.blocks[i].w_out, v.blocks[i].b_out, a.up_w, a.up_b, a.scale, a.wk_out, a.bk_out, D, D, d, 0));
         }
+        if ((int)v.blocks.size() > i && v.blocks[i].w_out && v.blocks[i].wf_qkv) {
+            std::vector<void*> sc;
+            float* q32 = nullptr;
+            keep_first(rc, dev_alloc(c, sc, (size_t)D * d * 4, (void**)&q32));
+            for (int k = 0; k < 2 && !rc; ++k) {
+                AdapterW::Fold& f = a.fold[k];
+                keep_first(rc, dev_alloc(c, own, (size_t)128 * D * 2, (void**)&f.down2));
+                keep_first(rc, dev_alloc(c, own, (size_t)D * (D + d) * 2, (void**)&f.wk_out));
+                keep_first(rc, dev_alloc(c, own, (size_t)3 * D * (D + d) * 2, (void**)&f.wq_cat));
+                keep_first(rc, dev_alloc(c, own, (size_t)d * d * 2, (void**)&f.g16));
+                keep_first(rc, dev_alloc(c, own, (size_t)d * 4, (void**)&f.qm));
+                if (rc) break;
+                const float* norms = k == 0 ? (a.extra.empty() ? a.dl[0][8] : a.extra.back().dl[8]) : a.dl[1][8];
+                hipError_t e = launch_adapter_fold(a.up_w, a.up_b, a.scale, norms, a.down_w, v.blocks[i].w_out, v.blocks[i].wf_qkv, D,
+                                                   q32, f.down2, f.wk_out, f.wq_cat, f.qm, f.g16, 0);
+                if (e == hipSuccess) e = hipDeviceSynchronize();
+                if (e != hipSuccess) rc = fail(c, HG_ERR_HIP, "adapter fold failed: %s", hipGetErrorString(e));
+            }
+            free_all(sc);
+            if (rc) return rc;
+        }
         a.present = true;
     }
     HG_HIP(hipDeviceSynchronize());
@@ -494,8 +524,11 @@ struct AdapterCall {
 // `kcat`: the adapter's update of the fp32 stream is left to the block's K-concatenated out-proj ([att | d] x [W_out | scale W_up]):
 // the decoder output d goes into columns D .. D+63 of the attention output buffer (row stride D + 64) and up_proj only refreshes
 // the centred fp16 copy + statistics that ln_1 needs (EPI_X16_SCALE_LN: no fp32 traffic at all)
+// `kcat` = 2: the adapter folded into the block's GEMMs altogether - nothing but down_proj and the decoder runs here; the
+// centred fp16 copy of the stream is expected in columns 0..D-1 of c->att (row stride D + 64), the decoder writes e beside it and
+// turns c->mr into the statistics of x + a; the block's QKV GEMM then takes [x16 | e] x [W'_qkv | W'_qkv Q]
 int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const AdapterCall& ac, hipStream_t s, bool fused,
-                bool kcat = false);
+                int kcat = 0);
 
 // LayerNorm folded into the GEMMs: the residual GEMMs (out-proj, c_proj) also emit the fp16 copy of the updated
 // rows and per-row partial statistics; the consuming GEMMs (QKV, c_fc) read that copy and apply mean / rstd in
@@ -557,6 +590,39 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         u.M = M; u.N = D; u.ldc = D; u.K = 64; u.lda = 64;
         fuse = adapter_fuse_on && gemm_duo_ok(EPI_SCALE_RESID_LN_F32, u);
     }
+    // How the adapter of block i reaches the stream (HG_ADAPTER_KCAT, default 2):
+    //   0  up_proj GEMM with a scaled-residual epilogue on the fp32 stream (+ fp16 copy + statistics)
+    //   1  the update rides in the block's K-concatenated out-proj; up_proj only refreshes the fp16 copy + statistics for ln_1
+    //   2  no up_proj at all: QKV takes [x16 | e] as well, ln_1's statistics come from the decoder (run_adapter)
+    static const int kcat_env = []() { const char* e = getenv("HG_ADAPTER_KCAT"); return e ? atoi(e) : 2; }();
+    std::vector<int> kmode(blocks.size(), 0);
+    bool any_k2 = false;
+    if (adapters && fuse)
+        for (size_t i = 0; i < blocks.size(); ++i) {
+            if (c->vit.adapters.size() <= i || !c->vit.adapters[i].present) continue;
+            const AdapterW& aw = c->vit.adapters[i];
+            if (row0_out && row0_env && i + 1 == blocks.size()) continue;
+            if (kcat_env >= 1 && aw.wk_out) kmode[i] = 1;
+            if (kcat_env >= 2 && aw.fold[ac->priors ? 0 : 1].wq_cat) {
+                AdapterDev ad{};
+                for (int k = 0; k < 2; ++k) ad.w16[k][0] = aw.w16[k][0];
+                GemmArgs q{};
+                float dummy = 0.f;
+                q.cs = &dummy; q.mr = &dummy; q.M = M; q.K = D + 64; q.lda = D + 64; q.N = 3 * D; q.ldc = 3 * D;
+                if (adapter_decoder_mfma_ok(ad, ac->priors != nullptr, L, ac->N) && gemm_ln_ok(EPI_LN_BIAS_F16, q)) {
+                    kmode[i] = 2;
+                    any_k2 = true;
+                }
+            }
+        }
+    if (any_k2) {
+        int rc = ensure(c, c->att, rup(M, 256) * (size_t)(D + 64) * 2);
+        if (rc) return rc;
+        att = (half_t*)c->att.p;
+    }
+    // the centred fp16 copy a block's ln_1 reads: beside e in the out-proj operand buffer when its adapter is folded (mode 2)
+    auto h_of = [&](size_t i) { return i < blocks.size() && kmode[i] == 2 ? att : h; };
+    auto ldh_of = [&](size_t i) { return i < blocks.size() && kmode[i] == 2 ? D + 64 : D; };
     const int sld = 4 * (D / 256);
     float* mr = nullptr;
     float* mu = nullptr;
@@ -573,22 +639,22 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         mu = (float*)c->mu.p;
         muc = adapters ? (float*)c->muc.p : nullptr;
         stats = (float*)c->stats.p;
-        if (pre_w) HG_HIP(launch_layernorm_rowstats(x, pre_w, pre_b, h, mr, mu, muc, M, D, s, pre_pos, pre_cls, L));
-        else HG_HIP(launch_rowstats_cast(x, h, mr, mu, M, D, s, muc));
+        if (pre_w) HG_HIP(launch_layernorm_rowstats(x, pre_w, pre_b, h_of(0), mr, mu, muc, M, D, s, pre_pos, pre_cls, L, ldh_of(0)));
+        else {
+            if (kmode.size() && kmode[0] == 2) kmode[0] = 1;      // rowstats_cast writes dense rows
+            HG_HIP(launch_rowstats_cast(x, h, mr, mu, M, D, s, muc));
+        }
     } else if (pre_w) {
         HG_HIP(launch_layernorm_f32(x, pre_w, pre_b, x, M, D, s, pre_pos, pre_cls, L));
     }
     if (pre_w && trace) HG_HIP(launch_copy_rows(x, trace, n_seq, L, D, s));
     for (size_t i = 0; i < blocks.size(); ++i) {
         const BlockW& b = blocks[i];
-        // HG_ADAPTER_KCAT=0: the adapter's up_proj updates the fp32 stream itself (EPI_SCALE_RESID_LN_F32)
-        static const bool kcat_on = []() { const char* e = getenv("HG_ADAPTER_KCAT"); return !(e && e[0] == '0'); }();
-        bool kcat = false;
+        const int kcat = kmode[i];
         if (adapters && c->vit.adapters.size() > i && c->vit.adapters[i].present) {
             const AdapterW& aw = c->vit.adapters[i];
-            kcat = fuse && kcat_on && aw.wk_out && !(row0_out && row0_env && i + 1 == blocks.size());
             if (kcat) {
-                int rc = ensure(c, c->att, rup(M, 256) * (size_t)(D + 64) * 2);
+                int rc = ensure(c, c->att, rup(M, 256) * (size_t)(D + 64) * 2);      // (mode 2: sized before the loop)
                 if (rc) return rc;
                 att = (half_t*)c->att.p;
             }
@@ -600,7 +666,11 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         const size_t qoff = row0_last ? D : 0;
         GemmArgs g{};
         g.A = h; g.lda = D; g.out = qkv + qoff; g.ldc = 3 * D; g.M = M; g.N = 3 * D - (int)qoff; g.K = D;
-        if (fuse) {
+        if (fuse && kcat == 2) {      // ln_1(x + a) W^T: [x16 | e] x [W'_qkv | W'_qkv Q], the statistics are those of x + a
+            g.A = att; g.lda = D + 64; g.K = D + 64;
+            g.W = c->vit.adapters[i].fold[ac->priors ? 0 : 1].wq_cat; g.bias = b.bf_qkv; g.cs = b.cs_qkv; g.mr = mr;
+            HG_HIP(gemm(c, EPI_LN_BIAS_F16, g, s));
+        } else if (fuse) {
             g.W = b.wf_qkv + qoff * D; g.bias = b.bf_qkv + qoff; g.cs = b.cs_qkv + qoff; g.mr = mr;
             HG_HIP(gemm(c, EPI_LN_BIAS_F16, g, s));
         } else {
@@ -642,8 +712,10 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         HG_HIP(attention(c, qkv, att, n_seq, L, heads, causal, s, kcat ? D + 64 : 0));
         g = GemmArgs{};
         g.A = att; g.lda = D; g.W = b.w_out; g.bias = b.b_out; g.out = x; g.ldc = D; g.M = M; g.N = D; g.K = D;
-        if (kcat) {      // x += [att | d] [W_out | scale W_up]^T + (b_out + scale b_up): the adapter's update rides along
+        if (kcat == 1) {      // x += [att | d] [W_out | scale W_up]^T + (b_out + scale b_up): the adapter's update rides along
             g.lda = D + 64; g.K = D + 64; g.W = c->vit.adapters[i].wk_out; g.bias = c->vit.adapters[i].bk_out;
+        } else if (kcat == 2) {      // ... as [att | e] [W_out | Q]^T + b_out
+            g.lda = D + 64; g.K = D + 64; g.W = c->vit.adapters[i].fold[ac->priors ? 0 : 1].wk_out;
         }
         if (fuse) {
             g.out2 = h; g.stats = stats; g.stats_ld = sld; g.mu = mu;
@@ -665,7 +737,7 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         g = GemmArgs{};
         g.A = fc; g.lda = 4 * D; g.W = b.w_proj; g.bias = b.b_proj; g.out = x; g.ldc = D; g.M = M; g.N = D; g.K = 4 * D;
         if (fuse && i + 1 < blocks.size()) {      // the last block is followed by ln_post / ln_final on selected rows
-            g.out2 = h; g.stats = stats; g.stats_ld = sld; g.mu = mu;
+            g.out2 = h_of(i + 1); g.ld2 = ldh_of(i + 1); g.stats = stats; g.stats_ld = sld; g.mu = mu;
             HG_HIP(gemm(c, EPI_RESID_LN_F32, g, s));
             HG_HIP(launch_finalize_stats(stats, mr, mu, M, sld, 64, s, muc));
         } else {
@@ -688,7 +760,7 @@ int ensure_tower_ws(hg_ctx* c, int M, int D) {
 }
 
 int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const AdapterCall& ac, hipStream_t s, bool fused,
-                bool kcat) {
+                int kcat) {
     const int M = n_seq * L;
     float* x = (float*)c->x.p;
     half_t* h = (half_t*)c->h.p;
@@ -701,7 +773,12 @@ int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const Ada
     // down = relu(down_proj(x))  (CLIP_models_adapter_prior2.py:184-185)
     GemmArgs g{};
     g.A = h; g.lda = D; g.W = a.down_w; g.bias = a.down_b; g.out = c->ad32.p; g.ldc = 128; g.M = M; g.N = 128; g.K = D;
-    if (fused) {       // on the centred fp16 copy the residual GEMMs keep current: W (x16 + mu) + b
+    const AdapterW::Fold& fold = a.fold[ac.priors ? 0 : 1];
+    if (kcat == 2) {   // ... read from the out-proj operand buffer, with x16 Q in the padded columns (no ReLU there)
+        g.A = (const half_t*)c->att.p; g.lda = D + 64; g.W = fold.down2; g.n_split = 64;
+        g.cs = a.down_cs; g.mu = (const float*)c->muc.p;
+        HG_HIP(gemm(c, EPI_MU_BIAS_RELU_F32, g, s));
+    } else if (fused) {       // on the centred fp16 copy the residual GEMMs keep current: W (x16 + mu) + b
         g.cs = a.down_cs; g.mu = (const float*)c->muc.p;
         HG_HIP(gemm(c, EPI_MU_BIAS_RELU_F32, g, s));
     } else {
@@ -731,17 +808,21 @@ int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const Ada
         if (z > 0)
             for (int j = 0; j < 6; ++j) ad.w16[0][j] = a.extra[z - 1].w16[j];
         half_t* d16 = kcat ? (half_t*)c->att.p + D : (half_t*)c->ad16.p;
+        AdapterFoldDev fd{};
+        if (kcat == 2) { fd.g16 = fold.g16; fd.qm = fold.qm; fd.mr = (float*)c->mr.p; fd.inv_D = 1.0f / (float)D; }
         hipError_t e = launch_adapter_decoder((const float*)c->ad32.p, ad, ac.priors, ac.mask, n_seq, L, ac.priors ? ac.N : 0,
                                               (float*)c->adkv.p, d16, s,
-                                              z + 1 < n_chain ? (float*)c->ad32.p : nullptr, kcat ? D + 64 : 64);
+                                              z + 1 < n_chain ? (float*)c->ad32.p : nullptr, kcat ? D + 64 : 64,
+                                              kcat == 2 ? &fd : nullptr);
         if (e != hipSuccess)
             return fail(c, HG_ERR_HIP, "adapter decoder layer %d failed: %s", z, hipGetErrorString(e));
     }
+    if (kcat == 2) return HG_OK;      // the update itself happens in the block's QKV and out-proj GEMMs
     // x += up_proj(.) * scale   (adapter...:201-202, :456)
     g = GemmArgs{};
     g.A = (const half_t*)c->ad16.p; g.lda = 64; g.W = a.up_w; g.bias = a.up_b; g.pos = a.scale; g.out = x; g.ldc = D;
     g.M = M; g.N = D; g.K = 64;
-    if (fused && kcat) {   // the stream gets the update in out-proj; ln_1 needs the fp16 copy + statistics of x + a now
+    if (fused && kcat == 1) {   // the stream gets the update in out-proj; ln_1 needs the fp16 copy + statistics of x + a now
         const int sld = 4 * (D / 256);
         g.A = (const half_t*)c->att.p + D; g.lda = D + 64; g.out = nullptr;
         g.out2 = h; g.stats = (float*)c->stats.p; g.stats_ld = sld;

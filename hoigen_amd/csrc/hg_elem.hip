@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) void layernorm_rowstats_kernel(float* __restri
                                                                  float* __restrict__ mr, float* __restrict__ mu,
                                                                  float* __restrict__ muc, int M, int D,
                                                                  const float* __restrict__ pos, const float* __restrict__ cls,
-                                                                 int Lpos) {
+                                                                 int Lpos, int ld16) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= M) return;
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(256) void layernorm_rowstats_kernel(float* __restri
                 q2 += d * d;
                 h[e] = (half_t)d;
             }
-            reinterpret_cast<half4*>(x16 + (size_t)r * D)[c] = h;
+            reinterpret_cast<half4*>(x16 + (size_t)r * ld16)[c] = h;
         }
     }
     const float rstd2 = 1.0f / sqrtf(wave_sum(q2) / (float)D + 1e-5f);
@@ -633,10 +633,12 @@ __global__ __launch_bounds__(256) void layernorm_rowstats_kernel(float* __restri
     }
 }
 hipError_t launch_layernorm_rowstats(float* x, const float* w, const float* b, half_t* x16, float* mr, float* mu, float* muc,
-                                     int M, int D, hipStream_t s, const float* pos, const float* cls, int L) {
+                                     int M, int D, hipStream_t s, const float* pos, const float* cls, int L, int ld16) {
     if (M <= 0) return hipSuccess;
-    if (D % 4 || D > 256 * LN_MAXC || (pos && (!cls || L < 1))) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(layernorm_rowstats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, w, b, x16, mr, mu, muc, M, D, pos, cls, L);
+    if (!ld16) ld16 = D;
+    if (D % 4 || D > 256 * LN_MAXC || (pos && (!cls || L < 1)) || ld16 < D || ld16 % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_rowstats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, w, b, x16, mr, mu, muc, M, D, pos, cls, L,
+                       ld16);
     return hipGetLastError();
 }
 hipError_t launch_rowstats_cast(const float* x, half_t* x16, float* mr, float* mu, int M, int D, hipStream_t s, float* muc) {
@@ -691,6 +693,77 @@ hipError_t launch_concat_upproj(const half_t* w_out, const float* b_out, const h
                                 const float* scale, half_t* wk, float* bk, int N, int K, int d, hipStream_t s) {
     if (N <= 0) return hipSuccess;
     hipLaunchKernelGGL(concat_upproj_kernel, dim3(N), dim3(256), 0, s, w_out, b_out, up_w, up_b, scale, wk, bk, N, K, d);
+    return hipGetLastError();
+}
+
+// ---- adapter folded into the block's own GEMMs (weight-load time; DESIGN.md §4 "variant C") -------------------------
+// The decoder's last LayerNorm gives d = g3 * z + b3 with sum_i z_i = 0, so the adapter's update of row x is
+//   a = scale * (W_up d + b_up) = Q e,   e = [z_0 .. z_62, 1],
+//   Q[:, i] = g3_i P[:, i] - g3_63 P[:, 63]  (i < 63),   Q[:, 63] = P b3 + scale * b_up,   P = diag(scale) W_up
+// - no bias term left, which is what lets every consumer take `a` as 64 more K columns.
+__global__ __launch_bounds__(64) void adapter_q_kernel(const half_t* __restrict__ up_w, const float* __restrict__ up_b,
+                                                       const float* __restrict__ scale, const float* __restrict__ norms,
+                                                       float* __restrict__ q32, int D) {
+    const int j = blockIdx.x, i = threadIdx.x;
+    const float sc = scale[j];
+    const float* g3 = norms + 128;
+    const float* b3 = norms + 192;
+    __shared__ float P[64];
+    P[i] = sc * (float)up_w[(size_t)j * 64 + i];
+    __syncthreads();
+    float v;
+    if (i < 63) v = g3[i] * P[i] - g3[63] * P[63];
+    else {
+        v = sc * up_b[j];
+        for (int k = 0; k < 64; ++k) v = fmaf(b3[k], P[k], v);
+    }
+    q32[(size_t)j * 64 + i] = v;
+}
+// down2 [128, D]: rows 0..63 = down_w, rows 64+i = fp16(Q[:, i]);  wk [D, D+64] = [w_out | fp16(Q)];
+// wq [N3, D+64] = [wf_qkv | fp16(wf_qkv Q)]
+__global__ __launch_bounds__(256) void adapter_fold_down_kernel(const half_t* __restrict__ down_w, const float* __restrict__ q32,
+                                                                half_t* __restrict__ down2, int D) {
+    const int n = blockIdx.x;
+    for (int k = threadIdx.x; k < D; k += 256)
+        down2[(size_t)n * D + k] = n < 64 ? down_w[(size_t)n * D + k] : (half_t)q32[(size_t)k * 64 + (n - 64)];
+}
+__global__ __launch_bounds__(256) void adapter_fold_w_kernel(const half_t* __restrict__ w, const float* __restrict__ q32,
+                                                             half_t* __restrict__ wk, int K, int identity) {
+    const int n = blockIdx.x;
+    for (int k = threadIdx.x; k < K; k += 256) wk[(size_t)n * (K + 64) + k] = w[(size_t)n * K + k];
+    if (identity) {      // K == D, rows of w are rows of the stream: the update itself
+        if (threadIdx.x < 64) wk[(size_t)n * (K + 64) + K + threadIdx.x] = (half_t)q32[(size_t)n * 64 + threadIdx.x];
+        return;
+    }
+    __shared__ float part[4][64];
+    const int i = threadIdx.x & 63, c = threadIdx.x >> 6;
+    float acc = 0.f;
+    for (int j = c; j < K; j += 4) acc = fmaf((float)w[(size_t)n * K + j], q32[(size_t)j * 64 + i], acc);
+    part[c][i] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64) wk[(size_t)n * (K + 64) + K + i] = (half_t)((part[0][i] + part[1][i]) + (part[2][i] + part[3][i]));
+}
+// statistics operands from the fp16-rounded Q the GEMMs really use: qm[i] = sum_j Q[j][i], G = Q^T Q (fp16 [64][64])
+__global__ __launch_bounds__(64) void adapter_fold_g_kernel(const float* __restrict__ q32, float* __restrict__ qm,
+                                                            half_t* __restrict__ g16, int D) {
+    const int i = blockIdx.x, k = threadIdx.x;
+    float g = 0.f, m = 0.f;
+    for (int j = 0; j < D; ++j) {
+        const float a = (float)(half_t)q32[(size_t)j * 64 + i], b = (float)(half_t)q32[(size_t)j * 64 + k];
+        g = fmaf(a, b, g);
+        m += a;
+    }
+    g16[i * 64 + k] = (half_t)g;
+    if (k == 0) qm[i] = m;
+}
+hipError_t launch_adapter_fold(const half_t* up_w, const float* up_b, const float* scale, const float* norms,
+                               const half_t* down_w, const half_t* w_out, const half_t* wf_qkv, int D, float* q32,
+                               half_t* down2, half_t* wk_out, half_t* wq_cat, float* qm, half_t* g16, hipStream_t s) {
+    hipLaunchKernelGGL(adapter_q_kernel, dim3(D), dim3(64), 0, s, up_w, up_b, scale, norms, q32, D);
+    hipLaunchKernelGGL(adapter_fold_down_kernel, dim3(128), dim3(256), 0, s, down_w, q32, down2, D);
+    hipLaunchKernelGGL(adapter_fold_w_kernel, dim3(D), dim3(256), 0, s, w_out, q32, wk_out, D, 1);
+    hipLaunchKernelGGL(adapter_fold_w_kernel, dim3(3 * D), dim3(256), 0, s, wf_qkv, q32, wq_cat, D, 0);
+    hipLaunchKernelGGL(adapter_fold_g_kernel, dim3(64), dim3(64), 0, s, q32, qm, g16, D);
     return hipGetLastError();
 }
 

@@ -64,9 +64,15 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, int m, int n, f32x4 
         f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n);
         *dst = *dst + v * sc;
     } else if constexpr (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_RELU_F32 || EPI == EPI_MU_BIAS_RELU_F32) {
-        if constexpr (EPI == EPI_BIAS_RELU_F32 || EPI == EPI_MU_BIAS_RELU_F32) {
+        if constexpr (EPI == EPI_BIAS_RELU_F32) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+        }
+        if constexpr (EPI == EPI_MU_BIAS_RELU_F32) {      // n_split > 0 without out_hi: columns >= n_split stay linear
+            if (!(p.n_split && n >= p.n_split)) {         // (the adapter's cross-term columns ride in the padded half)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+            }
         }
         float* dst = (p.out_hi && n >= p.n_split) ? reinterpret_cast<float*>(p.out_hi) + (size_t)m * p.ldc + (n - p.n_split)
                                                   : reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n;
@@ -225,6 +231,8 @@ hipError_t launch_gemm(int epi, const GemmArgs& a, hipStream_t s) {
     if (epi == EPI_SCALE_RESID_LN_F32 || epi == EPI_X16_SCALE_LN)
         return gemm_duo_ok(epi, a) ? launch_gemm_duo(epi, a, s) : hipErrorInvalidValue;
     if (epi == EPI_MU_BIAS_RELU_F32) return launch_gemm_simple(epi, a, s);
+    if (epi == EPI_RESID_LN_F32 && a.ld2 && a.ld2 != a.ldc)      // fp16 copy with its own row stride: gemm_ring2 only
+        return gemm_ln_ok(epi, a) ? launch_gemm_ring2(epi, a, s) : hipErrorInvalidValue;
     const bool use_duo = duo >= 3 || (duo == 2 && epi != EPI_RESID_LN_F32) || (duo == 1 && epi == EPI_BIAS_RESID_F32);
     if (!force_simple && use_duo && gemm_duo_ok(epi, a)) return launch_gemm_duo(epi, a, s);
     const bool ln = (epi == EPI_LN_BIAS_F16 || epi == EPI_LN_BIAS_QGELU_F16 || epi == EPI_RESID_LN_F32 ||

@@ -465,7 +465,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                         const auto s0 = __builtin_amdgcn_permlane16_swap(ux[0], uy[0], false, false);
                         const auto s1 = __builtin_amdgcn_permlane16_swap(ux[1], uy[1], false, false);
                         const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
-                        if (INTERIOR || m < p.M) *reinterpret_cast<u32x4*>(out2 + (size_t)m * p.ldc + nb + 4 * (q & ~1)) = o;
+                        if (INTERIOR || m < p.M) *reinterpret_cast<u32x4*>(out2 + (size_t)m * p.ld2 + nb + 4 * (q & ~1)) = o;
                     }
             }
         } else {
@@ -587,7 +587,10 @@ static hipError_t launch_ring2_t(const GemmArgs& a, hipStream_t s) {
 // N*4 bytes of bias must fit behind the 144 KiB ring
 bool gemm_ring2_ok(const GemmArgs& a) { return gemm_ring_ok(a) && a.N <= 3072; }
 
-hipError_t launch_gemm_ring2(int epi, const GemmArgs& a, hipStream_t s) {
+hipError_t launch_gemm_ring2(int epi, const GemmArgs& a_in, hipStream_t s) {
+    GemmArgs a = a_in;
+    if (!a.ld2) a.ld2 = a.ldc;
+    if (a.ld2 % 8) return hipErrorInvalidValue;
     switch (epi) {
         case EPI_BIAS_F16: return launch_ring2_t<EPI_BIAS_F16>(a, s);
         case EPI_BIAS_QGELU_F16: return launch_ring2_t<EPI_BIAS_QGELU_F16>(a, s);

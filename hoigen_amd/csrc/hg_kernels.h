@@ -54,7 +54,8 @@ struct GemmArgs {
     const float* cs = nullptr;   // EPI_LN_*: [N] column sums of the folded weight
     const float* mr = nullptr;   // EPI_LN_*: [M][2] (row mean minus the centre of the fp16 copy, rstd)
     const float* mu = nullptr;   // EPI_RESID_LN: [M] centre subtracted from the fp16 copy (the row's previous mean)
-    half_t* out2 = nullptr;      // EPI_RESID_LN: fp16 copy of the updated rows, leading dimension ldc
+    half_t* out2 = nullptr;      // EPI_RESID_LN: fp16 copy of the updated rows, leading dimension ld2 (0 = ldc)
+    int ld2 = 0;                 //   a stride other than ldc exists in gemm_ring2 only (the dispatcher routes it there)
     float* stats = nullptr;      // EPI_RESID_LN: [M][stats_ld][2] partial (sum, sumsq) per row and wave column group
     int stats_ld = 0;            //   = 4 * N / 256
     // EPI_BIAS_F32 / EPI_BIAS_RELU_F32 with two destinations: columns >= n_split go to out_hi[m * ldc + (n - n_split)]
@@ -146,7 +147,7 @@ hipError_t launch_rowstats_cast(const float* x, half_t* x16, float* mr, float* m
 // x = LayerNorm(x; w, b) in place (fp32) followed by rowstats_cast of the result, in one pass (ln_pre of the vision tower)
 hipError_t launch_layernorm_rowstats(float* x, const float* w, const float* b, half_t* x16, float* mr, float* mu, float* muc,
                                      int M, int D, hipStream_t s, const float* pos = nullptr, const float* cls = nullptr,
-                                     int L = 1);
+                                     int L = 1, int ld16 = 0);      // ld16: row stride of x16 in halfs (0 = D)
 // stats [M][nt][2]: per column group of gw columns (sum, sum of squared deviations from the group mean)
 // -> mr [M][2] = (mean - mu[m], rstd) over the nt * gw columns, eps 1e-5, then mu[m] = mean (the centre the next
 // residual GEMM subtracts from its fp16 copy)
@@ -193,8 +194,23 @@ struct AdapterDev {      // device pointers, all fp32 except the two MFMA operan
 // itself) instead of out16, for the next decoder layer of the chain
 // ld16: row stride of out16 in halfs (64 = dense; D + 64 when the rows are the right-hand columns of the K-concatenated
 // out-proj operand [att | d])
+// fold (MFMA path, last layer of a chain only): the layer writes e = [z_0 .. z_62, 1] (norm3 without its affine part) instead
+// of d and replaces mr[row] = (mean_x - c, rstd_x) by the LayerNorm statistics of x + a, a = Q e (adapter_q_kernel); it reads
+// w' = x16 Q from columns 64..127 of down32
+struct AdapterFoldDev {
+    const half_t* g16 = nullptr;   // [64][64] fp16 Q^T Q
+    const float* qm = nullptr;     // [64] column sums of Q
+    float* mr = nullptr;           // [M][2], updated in place; null = off
+    float inv_D = 0.f;
+};
 hipError_t launch_adapter_decoder(const float* down32, const AdapterDev& ad, const float* priors,
                                   const uint8_t* mask, int B, int L, int N, float* kv, half_t* out16,
-                                  hipStream_t s, float* chain32 = nullptr, int ld16 = 64);
+                                  hipStream_t s, float* chain32 = nullptr, int ld16 = 64, const AdapterFoldDev* fold = nullptr);
+bool adapter_decoder_mfma_ok(const AdapterDev& ad, bool priors, int L, int N);
+// weight-load time: Q (scratch q32 [D][64]) and the operands that carry it: down2 [128, D], wk_out [D, D+64] = [w_out | Q],
+// wq_cat [3D, D+64] = [wf_qkv | wf_qkv Q], qm [64], g16 [64][64]; norms = the last decoder layer's {norm2.w, norm2.b, norm3.w, norm3.b}
+hipError_t launch_adapter_fold(const half_t* up_w, const float* up_b, const float* scale, const float* norms,
+                               const half_t* down_w, const half_t* w_out, const half_t* wf_qkv, int D, float* q32,
+                               half_t* down2, half_t* wk_out, half_t* wq_cat, float* qm, half_t* g16, hipStream_t s);
 
 }  // namespace hg

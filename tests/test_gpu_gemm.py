@@ -130,7 +130,7 @@ def _operands(M, N, K, seed):
 # ragged M, K-tile counts 4 / 5 / 6 / 12 / 48; (8192, 2048, .) fills exactly one round of 256x256 tiles (two-phase loop),
 # the others run the 128-row variants
 LN_SHAPES = [(197 * 12 + 5, 768, 768), (256 * 33 + 100, 768, 256), (2048 + 37, 768, 320), (1024 + 3, 2304, 384),
-             (4096 + 77, 768, 3072), (8192, 2048, 256), (8192 - 60, 2048, 768)]
+             (4096 + 77, 768, 3072), (8192, 2048, 256), (8192 - 60, 2048, 768), (197 * 12 + 5, 2304, 832)]
 
 
 @pytest.mark.parametrize("M,N,K", LN_SHAPES)
