@@ -211,12 +211,12 @@ __device__ __forceinline__ float sum_rows4(float x) {
 }
 
 // t[f][g] (+)= W[16g.., :] . X[16f.., :]^T over K = 32 * KS features; W global fp16 [.][ldw], X = LDS rows of pitch XP
-template <int G, int KS>
-__device__ __forceinline__ void linear_T(f32x4 (&t)[4][G], const half_t* __restrict__ W, int ldw, const half_t* X, int lane) {
+template <int G, int KS, int F>
+__device__ __forceinline__ void linear_T(f32x4 (&t)[F][G], const half_t* __restrict__ W, int ldw, const half_t* X, int lane) {
     const int r = lane & 15, q = lane >> 4;
-    half8 xf[4][KS];
+    half8 xf[F][KS];
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < F; ++f)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) xf[f][ks] = *reinterpret_cast<const half8*>(X + (16 * f + r) * XP + 32 * ks + 8 * q);
 #pragma unroll
@@ -225,23 +225,23 @@ __device__ __forceinline__ void linear_T(f32x4 (&t)[4][G], const half_t* __restr
         for (int ks = 0; ks < KS; ++ks) {
             const half8 wf = *reinterpret_cast<const half8*>(W + (size_t)(16 * g + r) * ldw + 32 * ks + 8 * q);
 #pragma unroll
-            for (int f = 0; f < 4; ++f) t[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[f][ks], t[f][g], 0, 0, 0);
+            for (int f = 0; f < F; ++f) t[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[f][ks], t[f][g], 0, 0, 0);
         }
 }
-template <int G>
-__device__ __forceinline__ void init_bias(f32x4 (&t)[4][G], const float* __restrict__ b, int lane) {
+template <int G, int F>
+__device__ __forceinline__ void init_bias(f32x4 (&t)[F][G], const float* __restrict__ b, int lane) {
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const f32x4 bv = *reinterpret_cast<const f32x4*>(b + 16 * g + 4 * (lane >> 4));
 #pragma unroll
-        for (int f = 0; f < 4; ++f) t[f][g] = bv;
+        for (int f = 0; f < F; ++f) t[f][g] = bv;
     }
 }
-template <int G>
-__device__ __forceinline__ void store_T(const f32x4 (&t)[4][G], half_t* X, int lane) {
+template <int G, int F>
+__device__ __forceinline__ void store_T(const f32x4 (&t)[F][G], half_t* X, int lane) {
     const int r = lane & 15, q = lane >> 4;
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < F; ++f)
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             half4 h;
@@ -251,11 +251,11 @@ __device__ __forceinline__ void store_T(const f32x4 (&t)[4][G], half_t* X, int l
         }
 }
 // LayerNorm over the 64 features of every token (eps 1e-5, biased variance), in place; AFFINE = false: normalised values only
-template <bool AFFINE = true>
-__device__ __forceinline__ void layer_norm_T(f32x4 (&t)[4][4], const float* __restrict__ w, const float* __restrict__ b, int lane) {
+template <bool AFFINE = true, int F>
+__device__ __forceinline__ void layer_norm_T(f32x4 (&t)[F][4], const float* __restrict__ w, const float* __restrict__ b, int lane) {
     const int q = lane >> 4;
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
+    for (int f = 0; f < F; ++f) {
         float s = 0.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) s += (t[f][g][0] + t[f][g][1]) + (t[f][g][2] + t[f][g][3]);
@@ -290,12 +290,14 @@ __device__ __forceinline__ int key_slot(int key) {
     return (key & ~31) + 8 * ((w & 15) >> 2) + 4 * (w >> 4) + (w & 3);
 }
 
-template <bool SELF>
+// F = 16-token tiles per wave: the workgroup has ceil(L / 16F) waves (F = 2: seven waves of 32 tokens at L = 197 - two
+// waves per SIMD hide each other's LDS round trips and weight fetches; F = 4: four waves of 64)
+template <bool SELF, int F>
 // `down` is not __restrict__: a chained layer (adapter_num_layers > 1) writes chain32 == down in place
-__global__ __launch_bounds__(256) void adapter_decoder_mfma(const float* down, int ld_down, DecW16 W,
+__global__ __launch_bounds__(F == 2 ? 512 : 256) void adapter_decoder_mfma(const float* down, int ld_down, DecW16 W,
                                                             const float* __restrict__ priors, const uint8_t* __restrict__ mask,
                                                             int L, int N, half_t* __restrict__ out16, float* chain32, int ld16,
-                                                            AdapterFoldDev F) {
+                                                            AdapterFoldDev FD) {
     extern __shared__ __attribute__((aligned(16))) char smem_ad[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -303,31 +305,31 @@ __global__ __launch_bounds__(256) void adapter_decoder_mfma(const float* down, i
     const int nkeys = SELF ? L : N;
     const int nkt = (nkeys + 15) >> 4;                  // key tiles of 16
     const int nkb = (nkt + 1) >> 1;                     // key blocks of 32
-    half_t* Xw = reinterpret_cast<half_t*>(smem_ad) + wave * 64 * XP;        // this wave's activation rows
+    half_t* Xw = reinterpret_cast<half_t*>(smem_ad) + wave * 16 * F * XP;        // this wave's activation rows
     half_t* Ks = reinterpret_cast<half_t*>(smem_ad) + 4 * 64 * XP;           // K [key][KP]
     half_t* VT = Ks + NKMAX * KP;                                            // V^T [feature][VP]
     half_t* Mem = VT + 64 * VP;                                              // prior tokens fp16 [32][XP] (prior case)
 
     // ---- this wave's 64 tokens: fp32 residual of the layer in registers, fp16 copy in LDS
-    f32x4 tgt[4][4];
-    int tok[4];
+    f32x4 tgt[F][4];
+    int tok[F];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-        tok[f] = wave * 64 + 16 * f + r;
+    for (int f = 0; f < F; ++f) {
+        tok[f] = wave * 16 * F + 16 * f + r;
         const size_t m = (size_t)seq * L + (tok[f] < L ? tok[f] : L - 1);
 #pragma unroll
         for (int g = 0; g < 4; ++g) tgt[f][g] = *reinterpret_cast<const f32x4*>(down + m * ld_down + 16 * g + 4 * q);
     }
     store_T<4>(tgt, Xw, lane);
     // ---- K and V of the memory tokens -> LDS (K row-major, V transposed with permuted key slots)
-    auto emit_kv = [&](const half_t* X, int key0) {       // 64 memory rows in X -> keys key0 ..
-        f32x4 kk[4][4], vv[4][4];
+    auto emit_kv = [&](const half_t* X, int key0) {       // 16 F memory rows in X -> keys key0 ..
+        f32x4 kk[F][4], vv[F][4];
         init_bias<4>(kk, W.bk, lane);
         init_bias<4>(vv, W.bv, lane);
         linear_T<4, 2>(kk, W.Wk, 64, X, lane);
         linear_T<4, 2>(vv, W.Wv, 64, X, lane);
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
+        for (int f = 0; f < F; ++f) {
             const int key = key0 + 16 * f + r;
             if (key < NKMAX) {
                 const int slot = key_slot(key);
@@ -344,11 +346,11 @@ __global__ __launch_bounds__(256) void adapter_decoder_mfma(const float* down, i
         }
     };
     if constexpr (SELF) {
-        emit_kv(Xw, wave * 64);                            // memory = the sequence's own tokens
+        emit_kv(Xw, wave * 16 * F);                            // memory = the sequence's own tokens
         __syncthreads();
     } else {
         // prior tokens [N <= 32][64] fp32 -> fp16 rows (rows >= N zero), then wave 0 projects them
-        for (int i = tid; i < 32 * 16; i += 256) {
+        for (int i = tid; i < 32 * 16; i += (int)blockDim.x) {
             const int row = i >> 4, c4 = (i & 15) * 4;
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
             if (row < N) v = *reinterpret_cast<const f32x4*>(priors + ((size_t)seq * N + row) * 64 + c4);
@@ -357,11 +359,11 @@ __global__ __launch_bounds__(256) void adapter_decoder_mfma(const float* down, i
             for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
             *reinterpret_cast<half4*>(Mem + row * XP + c4) = h;
         }
-        for (int i = tid; i < 32 * 16; i += 256) {          // rows 32..63 of the fragment reads: zeros
+        for (int i = tid; i < 32 * 16; i += (int)blockDim.x) {          // rows 32..63 of the fragment reads: zeros
             *reinterpret_cast<half4*>(Mem + (32 + (i >> 4)) * XP + (i & 15) * 4) = half4{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
         }
         __syncthreads();
-        if (wave == 0) emit_kv(Mem, 0);
+        if (wave * 16 * F < 32) emit_kv(Mem + wave * 16 * F * XP, wave * 16 * F);      // the 32 prior rows
         __syncthreads();
     }
     // masked keys as a bit set (wave-uniform): bit k of word k >> 5
@@ -380,20 +382,20 @@ __global__ __launch_bounds__(256) void adapter_decoder_mfma(const float* down, i
     }
 
     // ---- q = (Wq x + bq) / sqrt(32)
-    f32x4 t[4][4];
+    f32x4 t[F][4];
     init_bias<4>(t, W.bq, lane);
     linear_T<4, 2>(t, W.Wq, 64, Xw, lane);
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < F; ++f)
 #pragma unroll
         for (int g = 0; g < 4; ++g) t[f][g] *= 0.17677669529663687f;
     store_T<4>(t, Xw, lane);                                  // (the fp16 copy of the input is no longer needed)
     // ---- cross attention, 2 heads of 32
-    f32x4 att[4][4];
+    f32x4 att[F][4];
 #pragma unroll
     for (int hd = 0; hd < 2; ++hd) {
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
+        for (int f = 0; f < F; ++f) {
             const half8 qf = *reinterpret_cast<const half8*>(Xw + (16 * f + r) * XP + 32 * hd + 8 * q);
             f32x4 o0 = f32x4{0.f, 0.f, 0.f, 0.f}, o1 = o0;
             // pass 1: scores of every key tile -> running maximum (scores are recomputed in pass 2: one MFMA per tile)
@@ -442,18 +444,18 @@ __global__ __launch_bounds__(256) void adapter_decoder_mfma(const float* down, i
     init_bias<4>(t, W.bo, lane);
     linear_T<4, 2>(t, W.Wo, 64, Xw, lane);
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < F; ++f)
 #pragma unroll
         for (int g = 0; g < 4; ++g) tgt[f][g] += t[f][g];
     layer_norm_T(tgt, W.norms, W.norms + 64, lane);
     // ---- FFN 64 -> 128 (relu) -> 64, residual, norm3
     store_T<4>(tgt, Xw, lane);
     {
-        f32x4 hid[4][8];
+        f32x4 hid[F][8];
         init_bias<8>(hid, W.b1, lane);
         linear_T<8, 2>(hid, W.W1, 64, Xw, lane);
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
+        for (int f = 0; f < F; ++f)
 #pragma unroll
             for (int g = 0; g < 8; ++g)
 #pragma unroll
@@ -463,17 +465,17 @@ __global__ __launch_bounds__(256) void adapter_decoder_mfma(const float* down, i
     init_bias<4>(t, W.b2, lane);
     linear_T<4, 4>(t, W.W2, 128, Xw, lane);
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < F; ++f)
 #pragma unroll
         for (int g = 0; g < 4; ++g) tgt[f][g] += t[f][g];
-    if (F.mr) {
+    if (FD.mr) {
         // Folded adapter (hg_elem.hip adapter_q_kernel): the layer hands on e = [z_0 .. z_62, 1] (z = norm3 without its affine
         // part) - the block's QKV and out-proj GEMMs take the update a = Q e as 64 more K columns - and the statistics ln_1
         // needs of y = x + a, from those of x and three 64-wide products:
         //   sum_j a_j = e . qm,   sum_j (x_j - c) a_j = e . w'  (w' = x16 Q: columns 64.. of the down_proj GEMM),   sum_j a_j^2 = e^T G e
         layer_norm_T<false>(tgt, nullptr, nullptr, lane);
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
+        for (int f = 0; f < F; ++f) {
             if (q == 3) tgt[f][3][3] = 1.0f;
 #pragma unroll
             for (int g = 0; g < 4; ++g)
@@ -482,17 +484,17 @@ __global__ __launch_bounds__(256) void adapter_decoder_mfma(const float* down, i
         }
         store_T<4>(tgt, Xw, lane);
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
+        for (int f = 0; f < F; ++f)
 #pragma unroll
             for (int g = 0; g < 4; ++g) t[f][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-        linear_T<4, 2>(t, F.g16, 64, Xw, lane);
+        linear_T<4, 2>(t, FD.g16, 64, Xw, lane);
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
+        for (int f = 0; f < F; ++f) {
             const size_t m = (size_t)seq * L + (tok[f] < L ? tok[f] : L - 1);
             float sa = 0.f, cr = 0.f, qd = 0.f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 qmv = *reinterpret_cast<const f32x4*>(F.qm + 16 * g + 4 * q);
+                const f32x4 qmv = *reinterpret_cast<const f32x4*>(FD.qm + 16 * g + 4 * q);
                 const f32x4 wv = *reinterpret_cast<const f32x4*>(down + m * ld_down + 64 + 16 * g + 4 * q);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -506,12 +508,12 @@ __global__ __launch_bounds__(256) void adapter_decoder_mfma(const float* down, i
             qd = sum_rows4(qd);
             if (q == 0 && tok[f] < L) {
                 typedef float f32x2 __attribute__((ext_vector_type(2)));
-                f32x2* mrp = reinterpret_cast<f32x2*>(F.mr + 2 * m);
+                f32x2* mrp = reinterpret_cast<f32x2*>(FD.mr + 2 * m);
                 const f32x2 old = *mrp;                          // (mean_x - c, rstd_x)
                 const float var_x = 1.0f / (old[1] * old[1]) - 1e-5f;
-                const float dv = (2.0f * (cr - old[0] * sa) + (qd - sa * sa * F.inv_D)) * F.inv_D;
+                const float dv = (2.0f * (cr - old[0] * sa) + (qd - sa * sa * FD.inv_D)) * FD.inv_D;
                 const float var_y = fmaxf(var_x + dv, 0.f);
-                *mrp = f32x2{old[0] + sa * F.inv_D, 1.0f / sqrtf(var_y + 1e-5f)};
+                *mrp = f32x2{old[0] + sa * FD.inv_D, 1.0f / sqrtf(var_y + 1e-5f)};
             }
         }
     } else {
@@ -519,7 +521,7 @@ __global__ __launch_bounds__(256) void adapter_decoder_mfma(const float* down, i
     }
     if (chain32) {      // adapter_num_layers > 1: fp32, in the layout the next layer of the chain reads (rows of ld_down)
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
+        for (int f = 0; f < F; ++f)
             if (tok[f] < L) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
@@ -528,7 +530,7 @@ __global__ __launch_bounds__(256) void adapter_decoder_mfma(const float* down, i
         return;
     }
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < F; ++f)
         if (tok[f] < L) {
             half_t* dst = out16 + ((size_t)seq * L + tok[f]) * ld16;
 #pragma unroll
@@ -568,18 +570,27 @@ hipError_t launch_adapter_decoder(const float* down32, const AdapterDev& ad, con
         static bool attr_set_d[HG_MAX_DEVICES] = {};
         bool& attr_set = attr_set_d[current_device_index()];
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&adapter_decoder_mfma<true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&adapter_decoder_mfma<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            if (e != hipSuccess) return e;
+            const void* fns[4] = {reinterpret_cast<const void*>(&adapter_decoder_mfma<true, 2>),
+                                  reinterpret_cast<const void*>(&adapter_decoder_mfma<false, 2>),
+                                  reinterpret_cast<const void*>(&adapter_decoder_mfma<true, 4>),
+                                  reinterpret_cast<const void*>(&adapter_decoder_mfma<false, 4>)};
+            for (const void* fn : fns) {
+                hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                if (e != hipSuccess) return e;
+            }
             attr_set = true;
         }
-        if (priors)
-            hipLaunchKernelGGL((adapter_decoder_mfma<false>), dim3(B), dim3(256), lds, s, down32, 128, Wd, priors, mask, L, N, out16, chain32, ld16, F);
-        else
-            hipLaunchKernelGGL((adapter_decoder_mfma<true>), dim3(B), dim3(256), lds, s, down32, 128, Wd, priors, mask, L, L, out16, chain32, ld16, F);
+        // 16 F tokens per wave: F = 2 (seven waves at L = 197: prior 39 -> 30 us, self 67 -> 46 us per layer at B = 256; thirteen
+        // waves of 16 tokens: 37 / 46 us) unless HG_ADAPTER_TILES = 4 (four waves)
+        static const int tiles = []() { const char* e = getenv("HG_ADAPTER_TILES"); return e && atoi(e) == 4 ? 4 : 2; }();
+        const int nkeys = priors ? N : L;
+        const unsigned threads = 64u * (unsigned)((L + 16 * tiles - 1) / (16 * tiles));
+#define HG_DEC_LAUNCH(SELF_, F_)                                                                                              \
+    hipLaunchKernelGGL((adapter_decoder_mfma<SELF_, F_>), dim3(B), dim3(threads), lds, s, down32, 128, Wd, priors, mask, L, \
+                       nkeys, out16, chain32, ld16, F)
+        if (tiles == 2) { if (priors) HG_DEC_LAUNCH(false, 2); else HG_DEC_LAUNCH(true, 2); }
+        else { if (priors) HG_DEC_LAUNCH(false, 4); else HG_DEC_LAUNCH(true, 4); }
+#undef HG_DEC_LAUNCH
         return hipGetLastError();
     }
     if (chain32 || F.mr) return hipErrorInvalidValue;      // chained layers and the folded statistics exist only on the MFMA path

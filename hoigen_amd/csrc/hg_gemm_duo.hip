@@ -463,7 +463,6 @@ static hipError_t launch_duo_t(const GemmArgs& a, hipStream_t s) {
     const int n_cu = n_cu_d[dev_i];
     const int tiles_m = (a.M + 127) / 128, tiles_n = a.N / 256;
     const int n_tiles = tiles_m * tiles_n;
-    const int grid = n_tiles < 2 * n_cu ? n_tiles : 2 * n_cu;
     const size_t a_bytes = (size_t)tiles_m * 128 * a.lda * 2;
     static const int gsz_env = []() { const char* e = getenv("HG_RING_GSZ"); return e ? atoi(e) : 0; }();
     int gsz = gsz_env > 0 ? gsz_env : (int)((1536 * 1024) / ((size_t)512 * a.K));

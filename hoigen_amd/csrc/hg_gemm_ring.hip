@@ -396,7 +396,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             const int n = n0 + hb * 128 + wn * 32 + g2 * 16 + 4 * (lane >> 4);
             return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.out) + (size_t)chunk_row(rg) * p.ldc + n);
         };
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
         // One K-tile of the two-phase schedule.  KIND: 0 middle, 1 first of a tile (the previous epilogue's stores may be
         // pending), 2 second to last (LayerNorm statistics DMA), 3 last (residual prefetch).  K >= 256 makes the four
         // kinds distinct K-tiles, and every K-tile before the last two of a tile has two successors in the stream, so
