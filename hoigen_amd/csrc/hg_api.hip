@@ -126,6 +126,7 @@ struct hg_ctx {
     Cache cache[HG_MAX_CACHE_SLOTS];
     // workspace (grow-only)
     Buf x, h, qkv, att, fc, head16, tok32, small, i32, ad32, ad16, adkv, mr, mu, muc, stats, pre, pretab, cx, ca, ch, cf, cq;
+    Buf skws, skfl;      // stream-K workspace + flags of the residual GEMMs (GemmArgs::sk_ws); one launch at a time per context
     int max_chunk_img = 256;
     int max_chunk_txt = 640;
     int max_chunk_rows = 32768;
@@ -505,6 +506,24 @@ hipError_t gemm(hg_ctx* c, int epi, const GemmArgs& g, hipStream_t s) {
     return launch_gemm(epi, g, s);
 }
 
+// Stream-K for the residual GEMMs whose 256x256 tiles fill the chip unevenly (N = 768 at batch 256: 2.31 rounds): hands the
+// context's workspace to the launch when the shape qualifies.  Opt-in (HG_STREAMK=1): measured, it only ties the whole-tile
+// kernels (c_proj 286 = 286 us, out_proj 160 vs 125 us; DESIGN.md 4 "Round 3"), and it makes a row's bits depend on where its
+// tile falls in the launch (the K loop of some tiles is cut in two).
+int streamk(hg_ctx* c, int epi, GemmArgs& g, bool force = false) {
+    static const bool on = []() { const char* e = getenv("HG_STREAMK"); return e && e[0] == '1'; }();
+    if (!(on || force) || !gemm_streamk_shape(epi, g)) return HG_OK;
+    int n_cu = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) n_cu = prop.multiProcessorCount;
+    int rc = ensure(c, c->skws, (size_t)n_cu * GEMM_SK_WS_BYTES);
+    if (!rc) rc = ensure(c, c->skfl, (size_t)n_cu * GEMM_SK_FLAG_BYTES);      // (ensure() zeroes new memory: flags start at 0)
+    if (rc) return rc;
+    g.sk_ws = (float*)c->skws.p;
+    g.sk_flags = (int*)c->skfl.p;
+    return HG_OK;
+}
+
 hipError_t attention(hg_ctx* c, const half_t* qkv, half_t* out, int n_seq, int L, int heads, bool causal, hipStream_t s,
                      int ldo = 0) {
     ProfScope ps(c, s, HG_PROF_ATTENTION, n_seq, L, heads);
@@ -719,9 +738,11 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         }
         if (fuse) {
             g.out2 = h; g.stats = stats; g.stats_ld = sld; g.mu = mu;
+            if (int rc = streamk(c, EPI_RESID_LN_F32, g)) return rc;
             HG_HIP(gemm(c, EPI_RESID_LN_F32, g, s));
             HG_HIP(launch_finalize_stats(stats, mr, mu, M, sld, 64, s, muc));
         } else {
+            if (int rc = streamk(c, EPI_BIAS_RESID_F32, g)) return rc;
             HG_HIP(gemm(c, EPI_BIAS_RESID_F32, g, s));
         }
         g = GemmArgs{};
@@ -738,9 +759,11 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         g.A = fc; g.lda = 4 * D; g.W = b.w_proj; g.bias = b.b_proj; g.out = x; g.ldc = D; g.M = M; g.N = D; g.K = 4 * D;
         if (fuse && i + 1 < blocks.size()) {      // the last block is followed by ln_post / ln_final on selected rows
             g.out2 = h_of(i + 1); g.ld2 = ldh_of(i + 1); g.stats = stats; g.stats_ld = sld; g.mu = mu;
+            if (int rc = streamk(c, EPI_RESID_LN_F32, g)) return rc;
             HG_HIP(gemm(c, EPI_RESID_LN_F32, g, s));
             HG_HIP(launch_finalize_stats(stats, mr, mu, M, sld, 64, s, muc));
         } else {
+            if (int rc = streamk(c, EPI_BIAS_RESID_F32, g)) return rc;
             HG_HIP(gemm(c, EPI_BIAS_RESID_F32, g, s));
         }
         if (trace) HG_HIP(launch_copy_rows(x, trace + (size_t)(i + 1) * trace_stride, n_seq, L, D, s));
@@ -880,7 +903,8 @@ void hg_destroy(hg_ctx* c) {
     for (auto& m : c->mlp) free_all(m.owned);
     for (auto& m : c->cache) free_all(m.owned);
     Buf* bufs[] = {&c->x, &c->h, &c->qkv, &c->att, &c->fc, &c->head16, &c->tok32, &c->small, &c->i32,
-                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq};
+                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq,
+                   &c->skws, &c->skfl};
     for (Buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
@@ -1036,7 +1060,10 @@ int hg_test_gemm_ln(hg_ctx* c, const float* a, const float* w, const float* bias
         g.pos = scale;
     }
     hipError_t e;
-    if (kernel == 2) e = gemm_ln_ok(epi, g) ? launch_gemm_ring(epi, g, s) : hipErrorInvalidValue;
+    if (kernel == 4) {      // the 256x256 ring kernel with stream-K (falls back to whole tiles when the shape does not qualify)
+        if (int rc2 = streamk(c, epi, g, true)) return rc2;
+        e = gemm_ln_ok(epi, g) ? launch_gemm_ring(epi, g, s) : hipErrorInvalidValue;
+    } else if (kernel == 2) e = gemm_ln_ok(epi, g) ? launch_gemm_ring(epi, g, s) : hipErrorInvalidValue;
     else if (kernel == 3) e = gemm_duo_ok(epi, g) ? launch_gemm_duo(epi, g, s) : hipErrorInvalidValue;
     else e = launch_gemm(epi, g, s);
     if (e != hipSuccess) return fail(c, HG_ERR_HIP, "test gemm (ln) launch failed: %s", hipGetErrorString(e));
@@ -1113,7 +1140,8 @@ int hg_profile_end(hg_ctx* c, hg_prof_rec* recs, int max_recs, int32_t* n_recs) 
 int hg_workspace_bytes(hg_ctx* c, uint64_t* bytes) {
     if (!c || !bytes) return HG_ERR_INVALID;
     Buf* bufs[] = {&c->x, &c->h, &c->qkv, &c->att, &c->fc, &c->head16, &c->tok32, &c->small, &c->i32,
-                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq};
+                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq,
+                   &c->skws, &c->skfl};
     uint64_t t = 0;
     for (Buf* b : bufs) t += b->bytes;
     *bytes = t;

@@ -231,9 +231,9 @@ hipError_t launch_gemm(int epi, const GemmArgs& a, hipStream_t s) {
     if (epi == EPI_SCALE_RESID_LN_F32 || epi == EPI_X16_SCALE_LN)
         return gemm_duo_ok(epi, a) ? launch_gemm_duo(epi, a, s) : hipErrorInvalidValue;
     if (epi == EPI_MU_BIAS_RELU_F32) return launch_gemm_simple(epi, a, s);
-    if (epi == EPI_RESID_LN_F32 && a.ld2 && a.ld2 != a.ldc)      // fp16 copy with its own row stride: gemm_ring2 only
-        return gemm_ln_ok(epi, a) ? launch_gemm_ring2(epi, a, s) : hipErrorInvalidValue;
-    const bool use_duo = duo >= 3 || (duo == 2 && epi != EPI_RESID_LN_F32) || (duo == 1 && epi == EPI_BIAS_RESID_F32);
+    const bool own_ld2 = a.ld2 && a.ld2 != a.ldc;      // fp16 copy with its own row stride: the ring kernels only
+    const bool use_duo = !own_ld2 && !(a.sk_ws && gemm_streamk_shape(epi, a)) &&
+                         (duo >= 3 || (duo == 2 && epi != EPI_RESID_LN_F32) || (duo == 1 && epi == EPI_BIAS_RESID_F32));
     if (!force_simple && use_duo && gemm_duo_ok(epi, a)) return launch_gemm_duo(epi, a, s);
     const bool ln = (epi == EPI_LN_BIAS_F16 || epi == EPI_LN_BIAS_QGELU_F16 || epi == EPI_RESID_LN_F32 ||
                      epi == EPI_VAE_REPARAM_F32);

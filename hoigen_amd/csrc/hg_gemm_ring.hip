@@ -83,6 +83,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     constexpr int N1 = 2 * GA + 3 * GB, N2 = 3 * GA + 2 * GB;
     constexpr bool RLN = (EPI == EPI_RESID_LN_F32);    // residual + centred fp16 copy + LayerNorm statistics (MF = 4)
     constexpr bool RESID = (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_SCALE_RESID_F32 || RLN);
+    // Stream-K (256x256 residual kernels, GemmArgs::sk_ws): the K-tiles of an XCD's tile list are dealt out evenly to its
+    // workgroups as ONE contiguous range each, so a workgroup's first item may be the tail of a tile (k >= kb: its accumulators
+    // go to the workspace, "dump") and its last item the head of one (k < ke: it adds the partner's dump and runs the epilogue,
+    // "join").  N = 768 at batch 256: 591 tiles = 2.31 rounds of work instead of 3 rounds of time.
+    constexpr bool SKC = (MF == 4 && RESID && !PH2);      // (the residual epilogues run the four-phase loop)
+    typedef unsigned u32x4_sk __attribute__((ext_vector_type(4)));
+    constexpr int SK_AUX = 1 | 16;      // sc0 sc1: the stream-K workspace bypasses the (per-XCD, mutually incoherent) L2s
     // epilogue store instructions per wave (vmcnt immediates are 6 bits: anything above is clamped, i.e. stricter)
     // (fp16 outputs leave as paired 16-byte stores: half as many; counting too many here would let the first waits of
     // the next tile pass before its operands have landed)
@@ -148,7 +155,49 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             tn = ngf * gsz + (rr - tm * grem);
         }
     };        // tiles slot, slot+G, ...
-    if (my_tiles <= 0) return;
+    // ---- stream-K work list.  Workgroups form "lanes" of tiles_n (one per column tile, neighbours on one XCD where the count
+    // allows): a lane walks a contiguous range of row panels, its members in step on the same panel - the A panel is fetched
+    // once and shared through L2 as in the whole-tile order (dealing K-tiles along the tile LIST instead makes every workgroup
+    // stream its panels alone, three times: c_proj 289 -> 424 us).  The panels' K-tiles are dealt evenly to the lanes.
+    const bool sk = SKC ? (p.sk_ws != nullptr) : false;
+    int sk_i0 = 0, sk_k0 = 0, sk_k1 = 0, sk_S = 0, sk_col = 0, sk_partner = 0, n_items = my_tiles;
+    if constexpr (SKC) {
+        if (sk) {
+            const int w = (bid & 7) * cpx + (bid >> 3);      // XCD-major linear index
+            const int lanes = G / tiles_n;
+            if (w >= lanes * tiles_n) return;                // spare workgroups (256 = 85 lanes of 3 + 1)
+            const int lane_id = w / tiles_n;
+            sk_col = w - lane_id * tiles_n;
+            const int w2 = w + tiles_n;                      // same column tile, next lane: dumps the tail this one joins
+            sk_partner = (w2 % cpx) * 8 + w2 / cpx;
+            const long long tot = (long long)tiles_m_all * nk;
+            auto cut = [&](int j) -> long long {      // snapped to 4 K-tiles inside a tile: every part has >= 4
+                if (j >= lanes) return tot;
+                const long long c = tot * j / lanes, rr = c % nk;
+                return c - rr + ((rr + 2) & ~3LL);
+            };
+            const long long lo = cut(lane_id), hi = cut(lane_id + 1);
+            sk_i0 = (int)(lo / nk);
+            sk_k0 = (int)(lo % nk);
+            sk_k1 = (int)(hi % nk);
+            n_items = (int)(hi / nk) - sk_i0 + (sk_k1 ? 1 : 0);
+            sk_S = (int)(hi - lo);
+        }
+    }
+    // item e of this workgroup: its tile and K-tile range [kb, ke)
+    auto item_get = [&](int e, int& tm, int& tn, int& kb, int& ke) {
+        kb = 0;
+        ke = nk;
+        if (sk) {
+            tm = sk_i0 + e;
+            tn = sk_col;
+            if (e == 0) kb = sk_k0;
+            if (e == n_items - 1 && sk_k1) ke = sk_k1;
+        } else {
+            tile_of(slot + e * cpx, tm, tn);
+        }
+    };
+    if (n_items <= 0) return;
     // De-synchronised epilogues: all tiles take the same time, so every CU would store (and, for the residual
     // epilogue, load) its output tile at the same moment - HBM idles during the K loops and saturates during
     // the epilogues.  Workgroups that own one tile fewer than the fullest ones have a tile time of slack; they
@@ -156,14 +205,14 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     {
         const int dunit = mode >> 8;                               // estimated cycles per K-tile, 0 = off
         const int max_tiles = (T8 + cpx - 1) / cpx;
-        if (dunit > 0 && my_tiles < max_tiles) {
+        if (dunit > 0 && my_tiles < max_tiles && !sk) {
             const unsigned h = ((unsigned)bid * 2654435761u) >> 24;   // 0..255
             const long long d = ((long long)(max_tiles - my_tiles) * nk * dunit * h) >> 8;
             const unsigned long long t0 = __builtin_amdgcn_s_memtime();
             while ((long long)(__builtin_amdgcn_s_memtime() - t0) < d) __builtin_amdgcn_s_sleep(32);
         }
     }
-    const int S = my_tiles * nk;                               // K-tiles in this workgroup's stream
+    const int S = sk ? sk_S : my_tiles * nk;                   // K-tiles in this workgroup's stream
 
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW =
@@ -194,18 +243,17 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
         }
     }
     // ---- load-stream state (wave-uniform): position ld_g, its tile origin and K offset
-    int ld_g = -1, ld_kt = nk - 1, ld_r = -1, ld_sA = 0, ld_sW = 0, ld_buf = 0;
+    int ld_g = -1, ld_kt = nk - 1, ld_ke = nk, ld_r = -1, ld_sA = 0, ld_sW = 0, ld_buf = 0;
     // WRAP: 0 = the stream stays inside its tile, 1 = it moves to the next tile, 2 = decide at run time.  In the
     // two-phase loop the stream (two K-tiles ahead) wraps exactly when K-tile nk-2 is consumed.
     auto ld_advance = [&](auto WRAP_T) {
         constexpr int WRAP = decltype(WRAP_T)::value;
         ++ld_g;
         ++ld_kt;
-        if (WRAP == 1 || (WRAP == 2 && ld_kt == nk)) {
-            ld_kt = 0;
+        if (WRAP == 1 || (WRAP == 2 && ld_kt == ld_ke)) {
             ++ld_r;
             int tm, tn;
-            tile_of(slot + ld_r * cpx, tm, tn);
+            item_get(ld_r, tm, tn, ld_kt, ld_ke);
             ld_sA = (xmode & 1) ? 0 : tm * BM * p.lda * 2;     // mode 1 (timing experiment): every tile reads tile 0
             ld_sW = (xmode & 1) ? 0 : tn * 256 * p.K * 2;
         }
@@ -375,13 +423,48 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     // the previous tile lay inside M, i.e. issued every one of its E epilogue stores (a ragged tile may skip store
     // instructions whose rows are all masked: the waits that follow it then do not allow for any)
     bool prev_full = false;
-    for (int r = 0; r < my_tiles; ++r) {
-        int tm, tn;
-        tile_of(slot + r * cpx, tm, tn);
+    for (int r = 0; r < n_items; ++r) {
+        int tm, tn, kb_r, ke_r;
+        item_get(r, tm, tn, kb_r, ke_r);
+        const int klen = ke_r - kb_r;
+        const bool dump = SKC ? (sk && kb_r > 0) : false;      // tail of a tile: accumulators -> workspace, no epilogue
+        const bool join = SKC ? (sk && ke_r < nk) : false;     // head of a tile: + the partner's dump, then the epilogue
+        (void)join;
         const int m0 = tm * BM, n0 = tn * 256;
-        const bool post_ok = prev_full;
+        const bool post_ok = prev_full && !join;
         prev_full = m0 + BM <= p.M;
         zero_acc();
+        if constexpr (SKC) {
+            // join: the accumulators START from the partner's dump of this tile's tail (the next workgroup of this XCD's list
+            // wrote it as its FIRST item - long done) and the head's K-tiles are added on top; the loads go straight into the
+            // accumulator registers.  vmcnt is drained once: the counted waits of the K loop know nothing of these loads.
+            if (join) {
+                int* fl = p.sk_flags + sk_partner * 8 + wave;
+                // (bounded: a partner that never shows up - a launch on a second stream sharing this workspace - must not hang the
+                // GPU; the tile then comes out as NaN instead)
+                int spins = 0;
+                while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1 && spins < (1 << 22)) {
+                    __builtin_amdgcn_s_sleep(8);
+                    ++spins;
+                }
+                const bool lost = spins >= (1 << 22);
+                const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)p.sk_ws, 0, 0x7FFFFFFF, 0x00020000);
+                const int kbase = (sk_partner * 8 + wave) * (32 * 1024);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int f = 0; f < MF; ++f)
+#pragma unroll
+                            for (int g2 = 0; g2 < 2; ++g2)
+                                acc[a][b][f][g2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                    rsK, lane * 16, kbase + (((a * 2 + b) * MF + f) * 2 + g2) * 1024, SK_AUX));
+                wait_vm<0>();
+                if (lost) acc[0][0][0][0] = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+                if (lane == 0) __hip_atomic_store(fl, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+            }
+        }
         f32x4 xres[XPRE ? 2 : 1][XPRE ? 2 : 1][XPRE ? MF : 1][XPRE ? 2 : 1];
         // rolling residual window (ROLL): chunk c = ((ha * MF + f) * 2 + hb) * 2 + g2 is this lane's f32x4 of row
         // m0 + ha*BM/2 + wm*MF*16 + f*16 + (lane&15), columns n0 + hb*128 + wn*32 + g2*16 + 4*(lane>>4)
@@ -404,7 +487,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             constexpr int KIND = decltype(KIND_T)::value;
             const int buf = (g & 1) * STAGE;
             const bool post = post_ok;
-            const bool more = KIND < 2 || r + 1 < my_tiles;      // a K-tile two positions ahead exists
+            const bool more = KIND < 2 || r + 1 < n_items;       // a K-tile two positions ahead exists
             (void)post; (void)more;
             // Two phases per K-tile (32 MFMAs per segment, half the barriers):
             //   PA: fetch A0 W0 W1 (t); refill A1(t+1);               wait -> A1(t) landed;        quadrants (0,0) (0,1)
@@ -421,7 +504,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             }
             if (KIND < 3 || more) issue_A(1, 0, GA);      // A1 of position g+1 exists unless the stream ends here
             if constexpr (ROLL && KIND == 3) {
-                {      // first ROLL_W residual chunks (+ the first row group's centre) of this tile
+                if (!dump) {      // first ROLL_W residual chunks (+ the first row group's centre) of this tile
 #pragma unroll
                     for (int c = 0; c < ROLL_W; ++c) xw[c] = chunk_load(c);
                     if constexpr (RLN) muw[0] = p.mu[chunk_row(0)];
@@ -450,7 +533,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             if constexpr (KIND == 0) wait_vm<NP>();
             else if constexpr (KIND == 1) { if (post) wait_vm<NP + E>(); else wait_vm<NP>(); }
             else if constexpr (KIND == 2) { if (more) wait_vm<NP>(); else wait_vm<0>(); }
-            else { if (more) wait_vm<NP + R>(); else wait_vm<0>(); }
+            else { if (more) { if (dump) wait_vm<NP>(); else wait_vm<NP + R>(); } else wait_vm<0>(); }
             SEG_E(0);
             sync_fetch();
             mma(I0{}, I0{});
@@ -462,7 +545,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             if constexpr (KIND == 0) wait_vm<NP>();
             else if constexpr (KIND == 1) { if (post) wait_vm<NP + E>(); else wait_vm<NP>(); }
             else if constexpr (KIND == 2) { if (more) wait_vm<NP>(); else wait_vm<0>(); }
-            else { if (more) wait_vm<NP + R>(); else wait_vm<0>(); }
+            else { if (more) { if (dump) wait_vm<NP>(); else wait_vm<NP + R>(); } else wait_vm<0>(); }
             SEG_E(0);
             sync_fetch();
             mma(I1{}, I1{});
@@ -477,7 +560,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             using K3 = std::integral_constant<int, 3>;
             ph2_ktile(K1{});
             HG_TR(r == 2);
-            for (int kt = 1; kt < nk - 2; ++kt) {
+            for (int kt = 1; kt < klen - 2; ++kt) {
                 ph2_ktile(K0{});
                 HG_TR((r == 1 && kt >= nk - 5) || (r == 2 && kt <= 4));
             }
@@ -486,11 +569,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             ph2_ktile(K3{});
             HG_TR(r == 1);
         } else {
-        for (int kt = 0; kt < nk; ++kt, ++g) {
+        for (int kt = 0; kt < klen; ++kt, ++g) {
             const int buf = (g & 1) * STAGE;
             const bool more = g + 2 < S;          // a K-tile two positions ahead exists
             const bool post = post_ok;             // epilogue stores of the previous tile may still be pending
-            const bool xl = (XPRE || ROLL) && kt == nk - 1;  // residual rows are fetched during the last K-tile
+            const bool xl = (XPRE || ROLL) && kt == klen - 1 && !dump;  // residual rows are fetched during the last K-tile
             // ---------------- P1: fetch A0(t), W0(t); refill A1(t+1); then quadrant (0,0)
             read_A(0, buf);
             read_W(I0{}, buf);
@@ -499,7 +582,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                 // ahead of the last one: by the last P4's counted wait it is more than N1 operations old, and that
                 // phase's barriers publish it to every wave before the epilogue (the waits run one operation
                 // stricter until it has retired)
-                if (kt == nk - 2 && lane < BM / 16)
+                if (kt == klen - 2 && lane < BM / 16)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsM, (HG_LDS void*)(smem + MR_OFF + wave * BM), 16, lane * 16,
                                                              (m0 + wave * (BM / 8)) * 8, 0, 0);
             }
@@ -569,6 +652,32 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             mma(I1{}, I0{});
             sync_mma();
                             }
+        }
+        if constexpr (SKC) {
+            // workspace: per (workgroup, wave) 32 chunks of 64 lanes x 16 B, in accumulator order - dump and join use the same
+            // (wave, lane) -> element map, so each wave hands over to the same wave of the partner: one flag per wave, no barrier
+            if (dump) {
+                // (buffer stores with a scalar offset per chunk: 32 per-chunk address pairs would not fit the register file)
+                const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)p.sk_ws, 0, 0x7FFFFFFF, 0x00020000);
+                const int kbase = (bid * 8 + wave) * (32 * 1024);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int f = 0; f < MF; ++f)
+#pragma unroll
+                            for (int g2 = 0; g2 < 2; ++g2)
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_sk, acc[a][b][f][g2]), rsK, lane * 16,
+                                                                       kbase + (((a * 2 + b) * MF + f) * 2 + g2) * 1024, SK_AUX);
+                // release without cache maintenance: the dump is written through (sc0 sc1) and read back the same way, so all it
+                // takes is the stores' acknowledgement - an agent-scope fence would write back / invalidate the XCD's whole L2 once
+                // per wave (measured: +80-90 us per launch).  (Drains vmcnt: the next item's operands have landed too.)
+                wait_vm<0>();
+                if (lane == 0) __hip_atomic_store(p.sk_flags + bid * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                prev_full = false;      // nothing of this item is in flight any more
+                continue;
+            }
         }
         // ---------------- epilogue of tile r (the ring keeps prefetching the next tile meanwhile)
         SEG_B(7);
@@ -787,7 +896,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
                         const auto s1 = __builtin_amdgcn_permlane16_swap(ux[1], uy[1], false, false);
                         const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
                         const int nc = n0 + hb * 128 + wn * 32 + ((q & 1) ? 16 : 0) + 4 * (q & ~1);
-                        if (m < p.M) *reinterpret_cast<u32x4*>(p.out2 + (size_t)m * p.ldc + nc) = o;
+                        if (m < p.M) *reinterpret_cast<u32x4*>(p.out2 + (size_t)m * p.ld2 + nc) = o;
                     }
                 }
             }
@@ -839,8 +948,18 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
 #endif
 }
 
+// stream-K needs >= 2 rounds of 256x256 tiles (a workgroup's range spans more than one tile) and K-tiles in fours
+// (lanes of N / 256 workgroups walk the row panels: at least two panels per lane, K-tiles in fours)
+static bool streamk_shape(const GemmArgs& a) {
+    const int nk = a.K / 64, tiles_m = (a.M + 255) / 256, tiles_n = a.N / 256;
+    return nk % 4 == 0 && nk >= 8 && tiles_n >= 1 && tiles_n <= 8 && tiles_m >= 2 * (256 / tiles_n);
+}
+
 template <int MF, int EPI, bool PH2 = false>
-static hipError_t launch_ring_t(const GemmArgs& a, hipStream_t s) {
+static hipError_t launch_ring_t(const GemmArgs& a_in, hipStream_t s) {
+    GemmArgs a = a_in;
+    if (!a.ld2) a.ld2 = a.ldc;
+    constexpr bool SKC = MF == 4 && !PH2 && (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_SCALE_RESID_F32 || EPI == EPI_RESID_LN_F32);
     constexpr int BM = 64 * MF;
     constexpr int RING = 2 * (2 * MF * 4096 + 2 * 16384);
     constexpr bool LNC = (EPI == EPI_LN_BIAS_F16 || EPI == EPI_LN_BIAS_QGELU_F16);
@@ -875,6 +994,8 @@ static hipError_t launch_ring_t(const GemmArgs& a, hipStream_t s) {
         if (g8 < grid) grid = g8;
     }
     if (const char* e = getenv("HG_RING_GRID")) { const int v = atoi(e); if (v >= 8 && v <= n_cu && v <= n_tiles) grid = v; }
+    if (SKC && a.sk_ws && a.sk_flags && streamk_shape(a) && n_cu >= 8 && tiles_m >= 2 * ((n_cu & ~7) / tiles_n)) grid = n_cu & ~7;   // every CU, equal shares
+    else a.sk_ws = nullptr;
     const size_t a_bytes = (size_t)tiles_m * BM * a.lda * 2;      // A is allocated with rows padded to 256
     static const int mode = []() {
         const char* e = getenv("HG_RING_MODE");
@@ -963,6 +1084,10 @@ bool gemm_ring_ok(const GemmArgs& a) {
     return true;
 }
 
+bool gemm_streamk_shape(int epi, const GemmArgs& a) {
+    return (epi == EPI_BIAS_RESID_F32 || epi == EPI_SCALE_RESID_F32 || epi == EPI_RESID_LN_F32) && gemm_ring_ok(a) && streamk_shape(a);
+}
+
 bool gemm_ln_ok(int epi, const GemmArgs& a) {
     if (!gemm_ring_ok(a)) return false;
     if (epi == EPI_VAE_REPARAM_F32) return a.out && a.out_hi && a.out2 && a.pos && a.ldc * 2 == a.N;
@@ -989,6 +1114,8 @@ hipError_t launch_gemm_ring(int epi, const GemmArgs& a, hipStream_t s) {
     // (fp16 copy + statistics: 387 MB per launch) the epilogue is an HBM burst of every CU at once, and three big
     // bursts overlap worse than five small ones (K = 768: 154 vs 127 us; K = 3072: 300 vs 303): keep 128 rows.
     if (resid && epi != EPI_RESID_LN_F32 && t256 >= 256 && (double)rounds <= 0.8 * rounds128 + 1e-9) big = true;
+    const bool sk = resid && a.sk_ws && a.sk_flags && streamk_shape(a);      // stream-K exists in the 256x256 kernel only
+    if (sk) big = true;
     if (force_big == 1) big = true;
     if (force_big == 2 || force_big == 3) big = false;
     if (epi == EPI_RESID_LN_F32 && !big) return launch_gemm_ring2(epi, a, s);     // no 128-row variant in this kernel

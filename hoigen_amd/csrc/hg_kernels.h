@@ -64,7 +64,14 @@ struct GemmArgs {
     int n_split = 0;                     // multiple of 16
     float* out3 = nullptr;               // EPI_VAE_REPARAM_F32: z (fp32), leading dimension ldc; may be null
     unsigned long long* dbg = nullptr;   // diagnostics: s_memtime totals (HG_STAMPS build), normally null
+    // stream-K of the 256x256 residual kernels (hg_gemm_ring.hip): workspace of GEMM_SK_WS_BYTES per workgroup and 8 flags
+    // (zero between launches) per workgroup; null = whole tiles only.  One launch at a time per workspace.
+    float* sk_ws = nullptr;
+    int* sk_flags = nullptr;
 };
+constexpr size_t GEMM_SK_WS_BYTES = 256 * 1024, GEMM_SK_FLAG_BYTES = 8 * sizeof(int);
+// would launch_gemm run this residual GEMM as stream-K if given a workspace? (shape test only)
+bool gemm_streamk_shape(int epi, const GemmArgs& a);
 
 // Requirements: N % 128 == 0, K % 64 == 0, A readable for rows < M, 16-byte aligned rows.
 // A must be allocated with its row count padded to a multiple of 256 (the ring kernel's DMA reads whole

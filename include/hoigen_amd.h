@@ -262,7 +262,8 @@ int hg_test_gemm(hg_ctx*, const float* a, const float* w, const float* bias, flo
  *              per-row partial statistics -> finalize_stats -> mr_out [M][2] = (mean - mu[m], rstd), mu_out [M] = mean
  *   epi 12     (duo, K >= 64): as 10 with the update scaled per column: x += (acc + bias) * scale[n]
  * All pointers are device fp32; a / w are rounded to fp16 inside; out2 comes back as fp32.  kernel: 0 dispatcher, 2 ring
- * family, 3 duo.  Unused pointers may be NULL. */
+ * family, 3 duo, 4 ring family with the context's stream-K workspace (epi 10: the 256x256 kernel deals K-tiles, not tiles,
+ * to its workgroups when M / 256 * N / 256 >= 512 and K / 64 is a multiple of 4).  Unused pointers may be NULL. */
 int hg_test_gemm_ln(hg_ctx*, const float* a, const float* w, const float* bias, float* out, int M, int N, int K, int epi,
                     int kernel, const float* cs, const float* mr, const float* mu, const float* scale, float* out2,
                     float* mr_out, float* mu_out, void* stream);
