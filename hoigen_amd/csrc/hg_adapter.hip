@@ -292,12 +292,14 @@ __device__ __forceinline__ int key_slot(int key) {
 
 // F = 16-token tiles per wave: the workgroup has ceil(L / 16F) waves (F = 2: seven waves of 32 tokens at L = 197 - two
 // waves per SIMD hide each other's LDS round trips and weight fetches; F = 4: four waves of 64)
-template <bool SELF, int F>
+// DN: down_proj runs here as well (AdapterDownDev): the workgroup owns its sequence's rows, so relu(W_down x + b) and the
+// cross-term columns x16 Q never travel through HBM as fp32 (26 MB each way per layer at B = 256) and one launch goes
+template <bool SELF, int F, bool DN>
 // `down` is not __restrict__: a chained layer (adapter_num_layers > 1) writes chain32 == down in place
 __global__ __launch_bounds__(F == 2 ? 512 : 256) void adapter_decoder_mfma(const float* down, int ld_down, DecW16 W,
                                                             const float* __restrict__ priors, const uint8_t* __restrict__ mask,
                                                             int L, int N, half_t* __restrict__ out16, float* chain32, int ld16,
-                                                            AdapterFoldDev FD) {
+                                                            AdapterFoldDev FD, AdapterDownDev DD) {
     extern __shared__ __attribute__((aligned(16))) char smem_ad[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -312,13 +314,111 @@ __global__ __launch_bounds__(F == 2 ? 512 : 256) void adapter_decoder_mfma(const
 
     // ---- this wave's 64 tokens: fp32 residual of the layer in registers, fp16 copy in LDS
     f32x4 tgt[F][4];
+    f32x4 wq[DN ? F : 1][4];      // DN: x16 Q of this wave's tokens (the cross term of the folded statistics)
     int tok[F];
 #pragma unroll
-    for (int f = 0; f < F; ++f) {
-        tok[f] = wave * 16 * F + 16 * f + r;
-        const size_t m = (size_t)seq * L + (tok[f] < L ? tok[f] : L - 1);
+    for (int f = 0; f < F; ++f) tok[f] = wave * 16 * F + 16 * f + r;
+    if constexpr (DN) {
+        // [relu(down_proj) | x16 Q] = [x16 + mu] W2^T + b over K = D: the 128 x 64 weight tile of a K-tile is staged through LDS
+        // (the K / V area is idle until emit_kv) for all waves, double buffered, the next tile's global loads in flight under the
+        // current tile's MFMAs; a wave's own rows come straight from global memory as MFMA fragments, one K-tile ahead.
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        constexpr int WP = 72;                       // halfs per staged weight row (64 + pad)
+        half_t* Wst = Ks;
+        const int nthr = (int)blockDim.x, nkd = DD.K >> 6;
+        size_t mrow[F], xrow[F];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) tgt[f][g] = *reinterpret_cast<const f32x4*>(down + m * ld_down + 16 * g + 4 * q);
+        for (int f = 0; f < F; ++f) {
+            mrow[f] = (size_t)seq * L + (tok[f] < L ? tok[f] : L - 1);
+            xrow[f] = mrow[f] * DD.ldx;
+        }
+        f32x4 t8[F][8];
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+#pragma unroll
+            for (int g = 0; g < 8; ++g) t8[f][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // 1024 pieces of 16 B per weight tile: three per thread (>= 384 threads).  Two register sets (tiles kt+1, kt+2 in flight),
+        // two LDS buffers, two fragment sets of the wave's own rows: every global load is issued two K-tiles before its use
+        u32x4 stA[3], stB[3];
+        auto ld_w = [&](u32x4 (&st)[3], int kt) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int pc = tid + j * nthr;
+                if (pc < 1024) st[j] = *reinterpret_cast<const u32x4*>(DD.w + (size_t)(pc >> 3) * DD.K + kt * 64 + (pc & 7) * 8);
+            }
+        };
+        auto st_w = [&](const u32x4 (&st)[3], int buf) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int pc = tid + j * nthr;
+                if (pc < 1024) *reinterpret_cast<u32x4*>(Wst + buf * 128 * WP + (pc >> 3) * WP + (pc & 7) * 8) = st[j];
+            }
+        };
+        half8 x0[F][2], x1[F][2];
+        auto ld_x = [&](half8 (&x)[F][2], int kt) {
+#pragma unroll
+            for (int f = 0; f < F; ++f)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) x[f][ks] = *reinterpret_cast<const half8*>(DD.x16 + xrow[f] + kt * 64 + 32 * ks + 8 * q);
+        };
+        auto compute = [&](int buf, const half8 (&x)[F][2]) {
+            const half_t* wt = Wst + buf * 128 * WP;
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const half8 wf = *reinterpret_cast<const half8*>(wt + (16 * g + r) * WP + 32 * ks + 8 * q);
+#pragma unroll
+                    for (int f = 0; f < F; ++f) t8[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, x[f][ks], t8[f][g], 0, 0, 0);
+                }
+        };
+        ld_w(stA, 0);
+        ld_x(x0, 0);
+        ld_x(x1, 1);
+        st_w(stA, 0);
+        ld_w(stA, 1);
+        if (2 < nkd) ld_w(stB, 2);
+        for (int kt = 0; kt < nkd; kt += 2) {        // (K / 64 is even: the launcher checks K % 128)
+            __syncthreads();                         // tile kt is in buffer 0; every wave is done with tile kt - 1 (buffer 1)
+            compute(0, x0);
+            st_w(stA, 1);                            // tile kt + 1
+            if (kt + 3 < nkd) ld_w(stA, kt + 3);
+            if (kt + 2 < nkd) ld_x(x0, kt + 2);
+            __syncthreads();
+            compute(1, x1);
+            if (kt + 2 < nkd) st_w(stB, 0);
+            if (kt + 4 < nkd) ld_w(stB, kt + 4);
+            if (kt + 3 < nkd) ld_x(x1, kt + 3);
+        }
+        __syncthreads();                             // the staging area becomes K / V
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const float mu = DD.muc[mrow[f]];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const f32x4 cs4 = *reinterpret_cast<const f32x4*>(DD.cs + 16 * g + 4 * q), b4 = *reinterpret_cast<const f32x4*>(DD.b + 16 * g + 4 * q);
+                f32x4 v = t8[f][g] + cs4 * mu + b4;  // W (x16 + mu) + b = acc + mu * cs + b
+                if (g < 4) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    tgt[f][g] = v;
+                } else {
+                    wq[f][g - 4] = v;
+                }
+            }
+            if (chain32 && tok[f] < L) {             // chained layers: the last one reads x16 Q from the fp32 buffer
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(chain32 + ((size_t)seq * L + tok[f]) * ld_down + 64 + 16 * g + 4 * q) = wq[f][g];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const size_t m = (size_t)seq * L + (tok[f] < L ? tok[f] : L - 1);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) tgt[f][g] = *reinterpret_cast<const f32x4*>(down + m * ld_down + 16 * g + 4 * q);
+        }
     }
     store_T<4>(tgt, Xw, lane);
     // ---- K and V of the memory tokens -> LDS (K row-major, V transposed with permuted key slots)
@@ -495,7 +595,9 @@ __global__ __launch_bounds__(F == 2 ? 512 : 256) void adapter_decoder_mfma(const
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 qmv = *reinterpret_cast<const f32x4*>(FD.qm + 16 * g + 4 * q);
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(down + m * ld_down + 64 + 16 * g + 4 * q);
+                f32x4 wv;
+                if constexpr (DN) wv = wq[f][g];
+                else wv = *reinterpret_cast<const f32x4*>(down + m * ld_down + 64 + 16 * g + 4 * q);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     sa = fmaf(tgt[f][g][e], qmv[e], sa);
@@ -543,9 +645,16 @@ __global__ __launch_bounds__(F == 2 ? 512 : 256) void adapter_decoder_mfma(const
         }
 }
 
+bool adapter_decoder_mfma_ok(const AdapterDev& ad, bool priors, int L, int N);
 static bool decoder_mfma_on() {
     static const bool on = []() { const char* e = getenv("HG_ADAPTER_MFMA"); return !(e && e[0] == '0'); }();
     return on;
+}
+// down_proj inside the decoder kernel: the MFMA path with 32 tokens per wave and at least six waves (L >= 161)
+bool adapter_decoder_fused_down_ok(const AdapterDev& ad, bool priors, int L, int N) {
+    static const bool tiles4 = []() { const char* e = getenv("HG_ADAPTER_TILES"); return e && atoi(e) == 4; }();
+    static const bool off = []() { const char* e = getenv("HG_ADAPTER_DOWN_FUSE"); return e && e[0] == '0'; }();
+    return !off && !tiles4 && adapter_decoder_mfma_ok(ad, priors, L, N) && 64 * ((L + 31) / 32) >= 384;
 }
 bool adapter_decoder_mfma_ok(const AdapterDev& ad, bool priors, int L, int N) {
     return decoder_mfma_on() && ad.w16[priors ? 0 : 1][0] && L <= NKMAX && (priors ? N <= 32 : true);
@@ -554,10 +663,13 @@ bool adapter_decoder_mfma_ok(const AdapterDev& ad, bool priors, int L, int N) {
 // down32 [M,128] fp32 (cols 0..63 = relu(down_proj(x))) -> out16 [M,64] fp16 = decoder layer output
 hipError_t launch_adapter_decoder(const float* down32, const AdapterDev& ad, const float* priors,
                                   const uint8_t* mask, int B, int L, int N, float* kv, half_t* out16,
-                                  hipStream_t s, float* chain32, int ld16, const AdapterFoldDev* fold) {
+                                  hipStream_t s, float* chain32, int ld16, const AdapterFoldDev* fold,
+                                  const AdapterDownDev* dn) {
     if (ld16 < AD || ld16 % 8) return hipErrorInvalidValue;
     AdapterFoldDev F{};
     if (fold && !chain32) F = *fold;
+    AdapterDownDev DDv{};
+    if (dn) DDv = *dn;
     const int which = priors ? 0 : 1;            // mhsa_layers.0 (prior) vs mhsa (self)
     const float* const* dl = ad.dl[which];
     const int Nmem = priors ? N : L;
@@ -570,10 +682,12 @@ hipError_t launch_adapter_decoder(const float* down32, const AdapterDev& ad, con
         static bool attr_set_d[HG_MAX_DEVICES] = {};
         bool& attr_set = attr_set_d[current_device_index()];
         if (!attr_set) {
-            const void* fns[4] = {reinterpret_cast<const void*>(&adapter_decoder_mfma<true, 2>),
-                                  reinterpret_cast<const void*>(&adapter_decoder_mfma<false, 2>),
-                                  reinterpret_cast<const void*>(&adapter_decoder_mfma<true, 4>),
-                                  reinterpret_cast<const void*>(&adapter_decoder_mfma<false, 4>)};
+            const void* fns[6] = {reinterpret_cast<const void*>(&adapter_decoder_mfma<true, 2, false>),
+                                  reinterpret_cast<const void*>(&adapter_decoder_mfma<false, 2, false>),
+                                  reinterpret_cast<const void*>(&adapter_decoder_mfma<true, 4, false>),
+                                  reinterpret_cast<const void*>(&adapter_decoder_mfma<false, 4, false>),
+                                  reinterpret_cast<const void*>(&adapter_decoder_mfma<true, 2, true>),
+                                  reinterpret_cast<const void*>(&adapter_decoder_mfma<false, 2, true>)};
             for (const void* fn : fns) {
                 hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
                 if (e != hipSuccess) return e;
@@ -585,10 +699,18 @@ hipError_t launch_adapter_decoder(const float* down32, const AdapterDev& ad, con
         static const int tiles = []() { const char* e = getenv("HG_ADAPTER_TILES"); return e && atoi(e) == 4 ? 4 : 2; }();
         const int nkeys = priors ? N : L;
         const unsigned threads = 64u * (unsigned)((L + 16 * tiles - 1) / (16 * tiles));
-#define HG_DEC_LAUNCH(SELF_, F_)                                                                                              \
-    hipLaunchKernelGGL((adapter_decoder_mfma<SELF_, F_>), dim3(B), dim3(threads), lds, s, down32, 128, Wd, priors, mask, L, \
-                       nkeys, out16, chain32, ld16, F)
-        if (tiles == 2) { if (priors) HG_DEC_LAUNCH(false, 2); else HG_DEC_LAUNCH(true, 2); }
+#define HG_DEC_LAUNCH(SELF_, F_)                                                                                                     \
+    hipLaunchKernelGGL((adapter_decoder_mfma<SELF_, F_, false>), dim3(B), dim3(threads), lds, s, down32, 128, Wd, priors, mask, L, \
+                       nkeys, out16, chain32, ld16, F, DDv)
+        if (dn) {      // down_proj fused: 32 tokens per wave, >= 384 threads (adapter_decoder_fused_down_ok)
+            if (tiles != 2 || threads < 384 || !dn->x16 || dn->K % 128 || dn->K < 256 || dn->ldx % 8) return hipErrorInvalidValue;
+            if (priors)
+                hipLaunchKernelGGL((adapter_decoder_mfma<false, 2, true>), dim3(B), dim3(threads), lds, s, down32, 128, Wd, priors, mask, L,
+                                   nkeys, out16, chain32, ld16, F, DDv);
+            else
+                hipLaunchKernelGGL((adapter_decoder_mfma<true, 2, true>), dim3(B), dim3(threads), lds, s, down32, 128, Wd, priors, mask, L,
+                                   nkeys, out16, chain32, ld16, F, DDv);
+        } else if (tiles == 2) { if (priors) HG_DEC_LAUNCH(false, 2); else HG_DEC_LAUNCH(true, 2); }
         else { if (priors) HG_DEC_LAUNCH(false, 4); else HG_DEC_LAUNCH(true, 4); }
 #undef HG_DEC_LAUNCH
         return hipGetLastError();

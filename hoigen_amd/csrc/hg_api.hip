@@ -793,26 +793,29 @@ int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const Ada
     const int Nmem = ac.priors ? ac.N : L;
     if (!rc) rc = ensure(c, c->adkv, (size_t)n_seq * Nmem * 64 * 4 * 2);
     if (rc) return rc;
-    // down = relu(down_proj(x))  (CLIP_models_adapter_prior2.py:184-185)
-    GemmArgs g{};
-    g.A = h; g.lda = D; g.W = a.down_w; g.bias = a.down_b; g.out = c->ad32.p; g.ldc = 128; g.M = M; g.N = 128; g.K = D;
-    const AdapterW::Fold& fold = a.fold[ac.priors ? 0 : 1];
-    if (kcat == 2) {   // ... read from the out-proj operand buffer, with x16 Q in the padded columns (no ReLU there)
-        g.A = (const half_t*)c->att.p; g.lda = D + 64; g.W = fold.down2; g.n_split = 64;
-        g.cs = a.down_cs; g.mu = (const float*)c->muc.p;
-        HG_HIP(gemm(c, EPI_MU_BIAS_RELU_F32, g, s));
-    } else if (fused) {       // on the centred fp16 copy the residual GEMMs keep current: W (x16 + mu) + b
-        g.cs = a.down_cs; g.mu = (const float*)c->muc.p;
-        HG_HIP(gemm(c, EPI_MU_BIAS_RELU_F32, g, s));
-    } else {
-        HG_HIP(launch_f32_to_f16(x, h, (size_t)M * D, s));
-        HG_HIP(gemm(c, EPI_BIAS_RELU_F32, g, s));
-    }
     AdapterDev ad{};
     ad.down_w = a.down_w; ad.down_b = a.down_b; ad.up_w = a.up_w; ad.up_b = a.up_b; ad.scale = a.scale;
     for (int k = 0; k < 2; ++k) {
         for (int j = 0; j < 12; ++j) ad.dl[k][j] = a.dl[k][j];
         for (int j = 0; j < 6; ++j) ad.w16[k][j] = a.w16[k][j];
+    }
+    // down = relu(down_proj(x))  (CLIP_models_adapter_prior2.py:184-185) - inside the decoder kernel when it can (folded mode)
+    const bool down_fused = kcat == 2 && adapter_decoder_fused_down_ok(ad, ac.priors != nullptr, L, ac.N);
+    const AdapterW::Fold& fold = a.fold[ac.priors ? 0 : 1];
+    GemmArgs g{};
+    if (!down_fused) {
+        g.A = h; g.lda = D; g.W = a.down_w; g.bias = a.down_b; g.out = c->ad32.p; g.ldc = 128; g.M = M; g.N = 128; g.K = D;
+        if (kcat == 2) {   // ... read from the out-proj operand buffer, with x16 Q in the padded columns (no ReLU there)
+            g.A = (const half_t*)c->att.p; g.lda = D + 64; g.W = fold.down2; g.n_split = 64;
+            g.cs = a.down_cs; g.mu = (const float*)c->muc.p;
+            HG_HIP(gemm(c, EPI_MU_BIAS_RELU_F32, g, s));
+        } else if (fused) {       // on the centred fp16 copy the residual GEMMs keep current: W (x16 + mu) + b
+            g.cs = a.down_cs; g.mu = (const float*)c->muc.p;
+            HG_HIP(gemm(c, EPI_MU_BIAS_RELU_F32, g, s));
+        } else {
+            HG_HIP(launch_f32_to_f16(x, h, (size_t)M * D, s));
+            HG_HIP(gemm(c, EPI_BIAS_RELU_F32, g, s));
+        }
     }
     // post-norm decoder layer(s) over the 64-wide bottleneck (adapter...:186-200); with adapter_num_layers > 1 the
     // prior path chains mhsa_layers.0 .. N-1, the intermediate activations staying fp32 in place
@@ -833,10 +836,15 @@ int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const Ada
         half_t* d16 = kcat ? (half_t*)c->att.p + D : (half_t*)c->ad16.p;
         AdapterFoldDev fd{};
         if (kcat == 2) { fd.g16 = fold.g16; fd.qm = fold.qm; fd.mr = (float*)c->mr.p; fd.inv_D = 1.0f / (float)D; }
+        AdapterDownDev dn{};
+        if (down_fused && z == 0) {
+            dn.x16 = (const half_t*)c->att.p; dn.ldx = D + 64; dn.K = D; dn.w = fold.down2; dn.b = a.down_b; dn.cs = a.down_cs;
+            dn.muc = (const float*)c->muc.p;
+        }
         hipError_t e = launch_adapter_decoder((const float*)c->ad32.p, ad, ac.priors, ac.mask, n_seq, L, ac.priors ? ac.N : 0,
                                               (float*)c->adkv.p, d16, s,
                                               z + 1 < n_chain ? (float*)c->ad32.p : nullptr, kcat ? D + 64 : 64,
-                                              kcat == 2 ? &fd : nullptr);
+                                              kcat == 2 ? &fd : nullptr, down_fused && z == 0 ? &dn : nullptr);
         if (e != hipSuccess)
             return fail(c, HG_ERR_HIP, "adapter decoder layer %d failed: %s", z, hipGetErrorString(e));
     }

@@ -210,10 +210,23 @@ struct AdapterFoldDev {
     float* mr = nullptr;           // [M][2], updated in place; null = off
     float inv_D = 0.f;
 };
+// dn (MFMA path, first layer of a chain): down_proj runs inside the kernel - [relu(down) | x16 Q] = [x16 + muc] w^T + b with
+// w [128, K] fp16 (AdapterW::Fold::down2), b / cs [128]; down32 is then only written (chain32: the fp32 hand-over to the next
+// layer, x16 Q in its columns 64..127) or not touched at all
+struct AdapterDownDev {
+    const half_t* x16 = nullptr;   // [M, ldx] centred fp16 copy of the stream
+    int ldx = 0, K = 0;
+    const half_t* w = nullptr;
+    const float* b = nullptr;
+    const float* cs = nullptr;
+    const float* muc = nullptr;    // [M] centre of the copy
+};
 hipError_t launch_adapter_decoder(const float* down32, const AdapterDev& ad, const float* priors,
                                   const uint8_t* mask, int B, int L, int N, float* kv, half_t* out16,
-                                  hipStream_t s, float* chain32 = nullptr, int ld16 = 64, const AdapterFoldDev* fold = nullptr);
+                                  hipStream_t s, float* chain32 = nullptr, int ld16 = 64, const AdapterFoldDev* fold = nullptr,
+                                  const AdapterDownDev* dn = nullptr);
 bool adapter_decoder_mfma_ok(const AdapterDev& ad, bool priors, int L, int N);
+bool adapter_decoder_fused_down_ok(const AdapterDev& ad, bool priors, int L, int N);
 // weight-load time: Q (scratch q32 [D][64]) and the operands that carry it: down2 [128, D], wk_out [D, D+64] = [w_out | Q],
 // wq_cat [3D, D+64] = [wf_qkv | wf_qkv Q], qm [64], g16 [64][64]; norms = the last decoder layer's {norm2.w, norm2.b, norm3.w, norm3.b}
 hipError_t launch_adapter_fold(const half_t* up_w, const float* up_b, const float* scale, const float* norms,
