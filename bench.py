@@ -21,6 +21,7 @@ Extra objects on the line:
                    and fraction of 8 TB/s (from the two untimed, fully instrumented steps).
   step_ms          median / p10 / p90 of the individual timed steps (events on the compute stream).
   class_rows_only  the library's default (last block on the class-token rows only), same protocol.
+  power            (N = 1) package power / shader clock while the headline step runs (rocm-smi beside an untimed burst).
   config3/config4  (N = 1) encode_text over the 600 HICO prompts and the CoOp-VAE on 100 000 rows, each with its own
                    CPU baseline sample.
   cpu_baseline     the CPU oracle (a port of the reference's CPU path, pinned to the reference's own outputs) timed on
@@ -155,6 +156,58 @@ def timed(fn, iters: int, warm: int = 2) -> float:
         ts.append(a.elapsed_time(b))
     ts.sort()
     return ts[len(ts) // 2]
+
+
+def power_sample(step, sync, seconds: float = 2.5):
+    """Package power and shader clock while the headline step runs (its own untimed burst after the timed regions): the step
+    sits at the package power cap (profiles/r03_power.txt), which is what the sustained clock - and with it every MFMA
+    fraction on this line - hangs on.  rocm-smi is polled from a thread; None when it is missing or prints nothing usable."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return None
+    # never under a profiler: its preloaded library would initialise the GPU inside every child process
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ):
+        return None
+    child_env = dict(os.environ)
+    samples, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            try:
+                txt = subprocess.run([exe, "--showpower", "--showclocks", "--showmaxpower"], capture_output=True, text=True,
+                                     timeout=10, env=child_env).stdout
+            except Exception:
+                return
+            w = re.search(r"GPU\[0\].*?Current Socket Graphics Package Power \(W\):\s*([0-9.]+)", txt)
+            c = re.search(r"GPU\[0\].*?sclk clock level:.*?\((\d+)Mhz\)", txt)
+            cap = re.search(r"GPU\[0\].*?Max Graphics Package Power \(W\):\s*([0-9.]+)", txt)
+            if w and c:
+                samples.append((float(w.group(1)), int(c.group(1)), float(cap.group(1)) if cap else None))
+
+    th = threading.Thread(target=poll, daemon=True)
+    t0 = time.perf_counter()
+    th.start()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(20):
+            step()
+        sync()
+        n += 20
+    stop.set()
+    th.join(timeout=15)
+    busy = [x for x in samples if x[0] > 0.5 * max(y[0] for y in samples)] if samples else []
+    if not busy:
+        return None
+    med = lambda v: sorted(v)[len(v) // 2]
+    return {"what": "rocm-smi polled beside an untimed burst of the headline step (samples above half the maximum power)",
+            "steps": n, "samples": len(busy),
+            "package_watts": {"median": med([x[0] for x in busy]), "min": min(x[0] for x in busy), "max": max(x[0] for x in busy)},
+            "sclk_mhz": {"median": med([x[1] for x in busy]), "min": min(x[1] for x in busy), "max": max(x[1] for x in busy)},
+            "cap_watts": busy[0][2], "nominal_sclk_mhz": 2400}
 
 
 def config3(model, dev, with_cpu: bool):
@@ -435,6 +488,14 @@ def run(args):
                 "e2e_frac": round(v2 / world * f2 / 1e12 / MFMA_PEAK_TFLOPS, 4),
                 "rel_l2_vs_all_rows": float(f"{rel:.3e}")}
         if world == 1:
+            if not args.no_extra_configs and not force_comm:
+                os.environ["HG_LAST_BLOCK_ROW0"] = "0"
+                pw = power_sample(step, lambda: torch.cuda.synchronize(dev))
+                os.environ["HG_LAST_BLOCK_ROW0"] = "1"
+                if pw is not None:
+                    pw["mfma_peak_at_sustained_clock_tflops"] = round(MFMA_PEAK_TFLOPS * pw["sclk_mhz"]["median"] / 2400.0, 1)
+                    pw["e2e_frac_of_that"] = round(line["roofline"]["e2e_tflops"] / pw["mfma_peak_at_sustained_clock_tflops"], 4)
+                    line["power"] = pw
             with_cpu = not args.no_cpu_baseline
             if with_cpu:
                 line["cpu_baseline"] = cpu_baseline()
