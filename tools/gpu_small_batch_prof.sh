@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-kernel statistics of encode_image at a small batch (BATCHES=32 by default)
 R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp; export BATCHES=${BATCHES:-32}
-rm -rf $R/gpurun_out/sb; rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/sb -- python3 $R/tools/batch_sweep.py 2>&1 | grep -E "^batch"
+rm -rf $R/gpurun_out/sb; rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/sb -- python3 $R/tools/bench_batch_sweep.py 2>&1 | grep -E "^\{"
 f=$(find $R/gpurun_out/sb -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv,sys
