@@ -165,6 +165,21 @@ def test_variant_c_prior_counts_and_masks_vs_oracle(n_prior, n_pad):
         check(got_l.permute(0, 2, 3, 1), want_l.permute(0, 2, 3, 1).numpy(), what=f"local N={n_prior} pad={n_pad}")
 
 
+def test_vitb16_variant_c_without_prior_folded_path_vs_oracle():
+    """No prior: the adapter's decoder attends to the sequence's own 197 tokens (`mhsa`, CLIP_models_adapter_prior2.py:196-199).
+    Three crops make M = 591 >= 512 rows, i.e. the production path (adapter folded into the block's GEMMs, self-attention decoder
+    with down_proj inside) - the reference fixture's no-prior case has two crops and runs the small-batch path."""
+    from oracle import clip_oracle as co
+    raw = synth.clip_state_dict(synth.VIT_B16, 10)
+    raw.update(synth.adapter_state_dict(synth.VIT_B16, 14))
+    m = build_model(synth.to_torch(raw), use_adapter=True, adapter_pos="all").to(dev())
+    img = torch.from_numpy(synth.crops(3, 224, seed=33))
+    want_g, want_l = co.visual_with_prior(co.as_tensors(raw), img, None, adapter_layers=range(12))
+    got_g, got_l = m.visual(img.to(dev()), None)
+    check(got_g, want_g.numpy(), what="global, no prior, ViT-B/16 x 3 crops")
+    check(got_l.permute(0, 2, 3, 1), want_l.permute(0, 2, 3, 1).numpy(), what="local, no prior, ViT-B/16 x 3 crops")
+
+
 def test_tiny_vae_chain_vs_reference(g1, tinyA):
     D = 128
     d = dev()
