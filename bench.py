@@ -22,6 +22,7 @@ Extra objects on the line:
   step_ms          median / p10 / p90 of the individual timed steps (events on the compute stream).
   class_rows_only  the library's default (last block on the class-token rows only), same protocol.
   power            (N = 1) package power / shader clock while the headline step runs (rocm-smi beside an untimed burst).
+  variant_c        (N = 1) the detector's call `visual(x, prior)` with instance adapters on the same crops.
   config3/config4  (N = 1) encode_text over the 600 HICO prompts and the CoOp-VAE on 100 000 rows, each with its own
                    CPU baseline sample.
   cpu_baseline     the CPU oracle (a port of the reference's CPU path, pinned to the reference's own outputs) timed on
@@ -208,6 +209,36 @@ def power_sample(step, sync, seconds: float = 2.5):
             "package_watts": {"median": med([x[0] for x in busy]), "min": min(x[0] for x in busy), "max": max(x[0] for x in busy)},
             "sclk_mhz": {"median": med([x[1] for x in busy]), "min": min(x[1] for x in busy), "max": max(x[1] for x in busy)},
             "cap_watts": busy[0][2], "nominal_sclk_mhz": 2400}
+
+
+def variant_c(dev, crops, ms_a: float):
+    """Variant C - `visual(x, prior)` with trained instance adapters, the detector's call (CLIP_models_adapter_prior2.py:489-506,
+    upt_tip_cache_model_free_finetune_distill3.py:1615) - on the same crops with 14 prior tokens (4 padded) per crop."""
+    import torch
+    from hoigen_amd import synth
+    from hoigen_amd.model import build_model
+    sd = synth.to_torch(synth.clip_state_dict(synth.VIT_B16, 0))
+    sd.update(synth.to_torch(synth.adapter_state_dict(synth.VIT_B16, 21)))
+    m = build_model(sd, use_adapter=True, adapter_pos="all").to(dev)
+    B, N = crops.shape[0], 14
+    g = torch.Generator(device=dev).manual_seed(4321)
+    pri = torch.randn(B, N, 64, device=dev, generator=g)
+    mask = torch.zeros(B, N, dtype=torch.bool, device=dev)
+    mask[:, N - 4:] = True
+    for _ in range(3):
+        out = m.visual(crops, (pri, mask))
+    torch.cuda.synchronize(dev)
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = m.visual(crops, (pri, mask))
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    assert torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all()
+    del m
+    return {"workload": f"visual(x, prior): adapters in all 12 blocks, {N} prior tokens, batch {B}; global [B,512] + local [B,512,14,14]",
+            "ms": round(ms, 4), "crops_per_s": round(B / ms * 1e3, 1), "over_variant_a_all_rows": round(ms / ms_a, 4),
+            "gflop_per_crop": round(35.127 + 0.1541 + 12 * 0.0494, 3)}
 
 
 def config3(model, dev, with_cpu: bool):
@@ -500,6 +531,9 @@ def run(args):
             if with_cpu:
                 line["cpu_baseline"] = cpu_baseline()
             if not args.no_extra_configs:
+                os.environ["HG_LAST_BLOCK_ROW0"] = "0"
+                line["variant_c"] = variant_c(dev, crops, ms_per_step)
+                os.environ["HG_LAST_BLOCK_ROW0"] = "1"
                 line["config3"] = config3(model, dev, with_cpu)
                 line["config4"] = config4(dev, with_cpu)
         print(json.dumps(line), flush=True)

@@ -65,6 +65,7 @@ def test_bench_line_schema_on_gpu():
     # (the table is timed launch by launch on its own steps: with 3 timed steps on a cold box it can exceed the step by a few per cent)
     assert 0.8 * d["ms_per_step"] < sum(by_kernel.values()) < 1.12 * d["ms_per_step"]
     assert d["config4"]["ms"] > 0 and d["config3"]["truncated"]["ms"] < d["config3"]["full_77_tokens"]["ms"]
+    assert 1.0 < d["variant_c"]["over_variant_a_all_rows"] < 1.3 and d["variant_c"]["crops_per_s"] > 0
 
 
 @pytest.mark.gpu
