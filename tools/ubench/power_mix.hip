@@ -116,10 +116,12 @@ __global__ __launch_bounds__(512, 2) void mix(const char* __restrict__ src, size
     if (s == 12345.678f) out[0] = s;
 }
 
+static size_t g_region_kib = 0;      // argv[3]: private region per workgroup in KiB (with bit 3): 512 -> 128 MB in all = Infinity Cache
+
 template <int MASK>
 static void run(const char* src, int grid, double seconds, float* out) {
     const bool hbm = MASK & 8;
-    const size_t region = hbm ? (size_t)16 << 20 : (size_t)1 << 20, stride = hbm ? region : 0;
+    const size_t region = hbm ? (g_region_kib ? g_region_kib << 10 : (size_t)16 << 20) : (size_t)1 << 20, stride = hbm ? region : 0;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mix<MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     const int ktiles = 20000;
     hipEvent_t e0, e1;
@@ -145,13 +147,15 @@ static void run(const char* src, int grid, double seconds, float* out) {
            (MASK & 1) ? "mfma " : "", (MASK & 2) ? "ds_read " : "", (MASK & 4) ? "dma-L2 " : "", (MASK & 8) ? "dma-HBM " : "",
            total_ms * 1e3 / ((double)launches * ktiles), flops / (total_ms * 1e-3) * 1e-12,
            (MASK & 2) ? 196608.0 * launches * ktiles / (total_ms * 1e-3) * 1e-9 : 0.0,
-           (MASK & 12) ? 65536.0 * launches * ktiles / (total_ms * 1e-3) * 1e-9 : 0.0, hbm ? "private 16 MiB regions" : "shared 1 MiB");
+           (MASK & 12) ? 65536.0 * launches * ktiles / (total_ms * 1e-3) * 1e-9 : 0.0,
+           hbm ? (g_region_kib ? "private regions of argv[3] KiB" : "private 16 MiB regions") : "shared 1 MiB");
     fflush(stdout);
 }
 
 int main(int argc, char** argv) {
     const int mask = argc > 1 ? atoi(argv[1]) : 1;
     const double seconds = argc > 2 ? atof(argv[2]) : 4.0;
+    if (argc > 3) g_region_kib = (size_t)atoi(argv[3]);
     int cus = 0;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
     char* src;
