@@ -295,7 +295,7 @@ def config4(dev, with_cpu: bool):
     z = torch.randn(R, 512, device=dev, generator=gen)
     ms_full = timed(lambda: V(x, eps), 10)
     ms_gen = timed(lambda: G(z), 10)
-    _, recs = _lib.profile(V._ctx.handle, _lib.HG_PROF_ALL, 64, lambda: V(x, eps))
+    _, recs = _lib.profile(V._slot.get(dev)[1], _lib.HG_PROF_ALL, 64, lambda: V(x, eps))
     out = {"workload": f"CoOp-VAE Encoder->reparameterise->Generator, {R} rows x 512 (BASELINE.json configs[3]); "
                        "inputs and the four outputs (mean, log_var, z, bias) fp32 in HBM",
            "ms": round(ms_full, 4), "rows_per_s": round(R / ms_full * 1e3, 0),

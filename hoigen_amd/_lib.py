@@ -15,7 +15,7 @@ from typing import Dict, Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 # HG_LIB_PATH: load another build of the same ABI (A/B timing of kernel variants inside one GPU session)
 LIB_PATH = os.environ.get("HG_LIB_PATH") or os.path.join(HERE, "csrc", "libhoigen_amd.so")
-HG_MAX_SLOTS = 4
+HG_MAX_SLOTS = 16
 HG_F32, HG_F16 = 0, 1
 
 

@@ -10,6 +10,7 @@ Inference only (no autograd through the kernels); tensors must live on a HIP dev
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -25,6 +26,57 @@ def weights_init(m):
     if isinstance(m, Linear):
         m.weight.data.normal_(0.0, 0.02)
         m.bias.data.fill_(0)
+
+
+class _Slot:
+    """One weight slot (``kind``: "vae" or "mlp") of the per-device context that every VAE-family module on that device shares:
+    one workspace however many Encoder / Generator / VAE / mlp_net objects exist (the three-branch sampler of
+    main_tip_finetune.py:759-824 holds nine).  The slot goes back to the pool when its module dies.  As with any native context:
+    one launch at a time per device, i.e. callers that use several streams serialise these modules themselves."""
+    _lock = threading.Lock()
+    _pools = {}          # device index -> {"ctx": _Ctx, "vae": [free slots], "mlp": [free slots]}
+
+    def __init__(self, kind: str):
+        self.kind, self.idx, self.slot = kind, None, None
+
+    def get(self, device: torch.device):
+        """-> (context, handle, slot, fresh): ``fresh`` = the slot was just taken, its weights must be (re)loaded."""
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        fresh = False
+        with _Slot._lock:
+            if self.idx != idx:
+                self._give()
+                pool = _Slot._pools.get(idx)
+                if pool is None:
+                    pool = _Slot._pools[idx] = {"ctx": _Ctx(), "vae": list(range(_lib.HG_MAX_SLOTS)),
+                                                "mlp": list(range(_lib.HG_MAX_SLOTS))}
+                if not pool[self.kind]:
+                    raise RuntimeError(f"hoigen_amd: more than {_lib.HG_MAX_SLOTS} live {self.kind} modules on cuda:{idx} "
+                                       "(HG_MAX_SLOTS in include/hoigen_amd.h)")
+                self.idx, self.slot, fresh = idx, pool[self.kind].pop(0), True
+            ctx = _Slot._pools[idx]["ctx"]
+        return ctx, ctx.get(device), self.slot, fresh
+
+    def _give(self):
+        if self.idx is not None and self.idx in _Slot._pools:
+            _Slot._pools[self.idx][self.kind].append(self.slot)
+        self.idx, self.slot = None, None
+
+    def __del__(self):
+        try:
+            with _Slot._lock:
+                self._give()
+        except Exception:      # pragma: no cover - interpreter shutdown
+            pass
+
+    def __deepcopy__(self, memo):      # a copied module takes its own slot
+        return _Slot(self.kind)
+
+    def __getstate__(self):
+        return {"kind": self.kind}
+
+    def __setstate__(self, state):
+        self.kind, self.idx, self.slot = state["kind"], None, None
 
 
 class _Seq(nn.Module):
@@ -54,7 +106,7 @@ class Encoder(nn.Module):
         self.mean = Linear(hidden, dim)
         self.log_var = Linear(hidden, dim)
         self.apply(weights_init)
-        self._ctx = _Ctx()
+        self._slot = _Slot("vae")
         self._sig = None
 
     def _weights(self, w: _lib.hg_vae_weights):
@@ -68,18 +120,20 @@ class Encoder(nn.Module):
     @torch.no_grad()
     def forward(self, x: torch.Tensor):
         _require_cuda(x, "Encoder input")
-        h = self._ctx.get(x.device)
+        ctx, h, slot, fresh = self._slot.get(x.device)
+        if fresh:
+            self._sig = None
         sig = _sig(self.parameters())
         if sig != self._sig:
             w = _lib.hg_vae_weights()
             self._weights(w)
-            self._ctx.check(_lib.lib().hg_load_vae(h, 0, C.byref(w)), "hg_load_vae")
+            ctx.check(_lib.lib().hg_load_vae(h, slot, C.byref(w)), "hg_load_vae")
             self._sig = sig
         xf = _f32(x)
         R = xf.shape[0]
         mean, logvar = torch.empty_like(xf), torch.empty_like(xf)
         zeros = torch.zeros_like(xf)          # eps = 0: z is not requested
-        self._ctx.check(_lib.lib().hg_vae_forward(h, 0, xf.data_ptr(), zeros.data_ptr(), R, mean.data_ptr(),
+        ctx.check(_lib.lib().hg_vae_forward(h, slot, xf.data_ptr(), zeros.data_ptr(), R, mean.data_ptr(),
                                                   logvar.data_ptr(), None, None, _stream_ptr(x.device)),
                         "hg_vae_forward")
         return mean, logvar
@@ -93,7 +147,7 @@ class Generator(nn.Module):
         self.dim, self.hidden = dim, hidden
         self.net = _Seq([(0, Linear(dim, hidden)), (2, Linear(hidden, dim))])
         self.apply(weights_init)
-        self._ctx = _Ctx()
+        self._slot = _Slot("vae")
         self._sig = None
 
     def _weights(self, w: _lib.hg_vae_weights):
@@ -106,16 +160,18 @@ class Generator(nn.Module):
     @torch.no_grad()
     def forward(self, z: torch.Tensor) -> torch.Tensor:
         _require_cuda(z, "Generator input")
-        h = self._ctx.get(z.device)
+        ctx, h, slot, fresh = self._slot.get(z.device)
+        if fresh:
+            self._sig = None
         sig = _sig(self.parameters())
         if sig != self._sig:
             w = _lib.hg_vae_weights()
             self._weights(w)
-            self._ctx.check(_lib.lib().hg_load_vae(h, 0, C.byref(w)), "hg_load_vae")
+            ctx.check(_lib.lib().hg_load_vae(h, slot, C.byref(w)), "hg_load_vae")
             self._sig = sig
         zf = _f32(z)
         out = torch.empty_like(zf)
-        self._ctx.check(_lib.lib().hg_generator(h, 0, zf.data_ptr(), zf.shape[0], out.data_ptr(),
+        ctx.check(_lib.lib().hg_generator(h, slot, zf.data_ptr(), zf.shape[0], out.data_ptr(),
                                                 _stream_ptr(z.device)), "hg_generator")
         return out
 
@@ -130,25 +186,27 @@ class VAE:
     def __init__(self, netE: Encoder, netG: Generator):
         self.netE, self.netG = netE, netG
         self._guard_modules = (netE, netG)
-        self._ctx = _Ctx()
+        self._slot = _Slot("vae")
         self._sig = None
 
     @_inference_only
     @torch.no_grad()
     def __call__(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None):
         _require_cuda(x, "VAE input")
-        h = self._ctx.get(x.device)
+        ctx, h, slot, fresh = self._slot.get(x.device)
+        if fresh:
+            self._sig = None
         sig = _sig(list(self.netE.parameters()) + list(self.netG.parameters()))
         if sig != self._sig:
             w = _lib.hg_vae_weights()
             self.netE._weights(w)
             self.netG._weights(w)
-            self._ctx.check(_lib.lib().hg_load_vae(h, 0, C.byref(w)), "hg_load_vae")
+            ctx.check(_lib.lib().hg_load_vae(h, slot, C.byref(w)), "hg_load_vae")
             self._sig = sig
         xf = _f32(x)
         ef = torch.randn_like(xf) if eps is None else _f32(eps)
         mean, logvar, z, bias = (torch.empty_like(xf) for _ in range(4))
-        self._ctx.check(_lib.lib().hg_vae_forward(h, 0, xf.data_ptr(), ef.data_ptr(), xf.shape[0], mean.data_ptr(),
+        ctx.check(_lib.lib().hg_vae_forward(h, slot, xf.data_ptr(), ef.data_ptr(), xf.shape[0], mean.data_ptr(),
                                                   logvar.data_ptr(), z.data_ptr(), bias.data_ptr(),
                                                   _stream_ptr(x.device)), "hg_vae_forward")
         return mean, logvar, z, bias
@@ -162,25 +220,27 @@ class mlp_net(nn.Module):
         self.dims = (input_dim, hidden_dim, output_dim)
         self.net = _Seq([(0, Linear(input_dim, hidden_dim)), (2, Linear(hidden_dim, hidden_dim)),
                          (4, Linear(hidden_dim, output_dim))])
-        self._ctx = _Ctx()
+        self._slot = _Slot("mlp")
         self._sig = None
 
     @_inference_only
     @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         _require_cuda(x, "mlp_net input")
-        h = self._ctx.get(x.device)
+        ctx, h, slot, fresh = self._slot.get(x.device)
+        if fresh:
+            self._sig = None
         sig = _sig(self.parameters())
         if sig != self._sig:
             t = _lib.tensor
             w = _lib.hg_mlp_weights(self.dims[0], self.dims[1], self.dims[2], t(self.net[0].weight),
                                     t(self.net[0].bias), t(self.net[2].weight), t(self.net[2].bias),
                                     t(self.net[4].weight), t(self.net[4].bias))
-            self._ctx.check(_lib.lib().hg_load_mlp(h, 0, C.byref(w)), "hg_load_mlp")
+            ctx.check(_lib.lib().hg_load_mlp(h, slot, C.byref(w)), "hg_load_mlp")
             self._sig = sig
         xf = _f32(x)
         out = torch.empty(xf.shape[0], self.dims[2], device=x.device, dtype=torch.float32)
-        self._ctx.check(_lib.lib().hg_mlp_net(h, 0, xf.data_ptr(), xf.shape[0], out.data_ptr(), _stream_ptr(x.device)),
+        ctx.check(_lib.lib().hg_mlp_net(h, slot, xf.data_ptr(), xf.shape[0], out.data_ptr(), _stream_ptr(x.device)),
                         "hg_mlp_net")
         return out
 

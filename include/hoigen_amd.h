@@ -127,7 +127,7 @@ typedef struct {
     hg_tensor w0, b0, w2, b2, w4, b4;
 } hg_mlp_weights;
 
-#define HG_MAX_SLOTS 4 /* independent VAE / mlp_net weight sets: hoi, human, object (+1) */
+#define HG_MAX_SLOTS 16 /* independent VAE / mlp_net weight sets per context: three branches (hoi, human, object) x Encoder, Generator, VAE + spares */
 
 /* ---- lifecycle ------------------------------------------------------------------------- */
 hg_ctx* hg_create(int device);                 /* NULL on failure (no HIP device)               */

@@ -352,3 +352,37 @@ def test_variant_c_adapter_folded_into_the_block_gemms_equals_separate_up_proj(t
                 print(f"adapter mode {mode} vs 0, {layers} layer(s), {name}: rel-L2 {e:.2e}")
                 assert e < 1e-3, f"mode {mode}, {layers} layer(s), {name}: rel-L2 {e:.2e}"
         assert not torch.equal(res["2"][layers][0], res["2"][layers][2])      # the prior matters
+
+
+def test_vae_family_modules_share_one_context_per_device():
+    """Encoder / Generator / VAE / mlp_net objects take weight slots of ONE native context per device (one workspace however many
+    modules: the three-branch sampler of main_tip_finetune.py:759-824 holds nine), give them back when they die, and say so when
+    a seventeenth is asked for."""
+    import gc
+    from hoigen_amd import _lib
+    d = dev()
+    gc.collect()
+    x = vae.l2_normalize(torch.randn(64, 512, device=d))
+    mods, outs = [], []
+    for k in range(5):                                   # five encoders with different weights, alive together
+        E = vae.Encoder().to(d).eval()
+        E.load_state_dict(synth.to_torch(synth.encoder_state_dict(50 + k)))
+        mods.append(E)
+        outs.append(E(x)[0].clone())
+    handles = {m._slot.get(d)[1] for m in mods}
+    assert len(handles) == 1, "one shared context"
+    assert len({m._slot.slot for m in mods}) == 5, "five different slots"
+    for k, E in enumerate(mods):                          # each still answers with its own weights
+        assert torch.equal(E(x)[0], outs[k])
+    assert not torch.equal(outs[0], outs[1])
+    # exhaustion is loud, and dead modules free their slots
+    extra = []
+    with pytest.raises(RuntimeError, match="live vae modules"):
+        for _ in range(_lib.HG_MAX_SLOTS + 1):
+            G = vae.Generator().to(d).eval()
+            G(torch.randn(4, 512, device=d))
+            extra.append(G)
+    del extra, G
+    gc.collect()
+    G = vae.Generator().to(d).eval()
+    assert G(torch.randn(4, 512, device=d)).shape == (4, 512)
