@@ -65,6 +65,8 @@ def parse_args():
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the config3 / config4 objects")
     ap.add_argument("--no-class-rows", action="store_true",
                     help="skip the second timed region (the library's default last block); for kernel traces of the headline alone")
+    ap.add_argument("--power", action="store_true",
+                    help="with --no-extra-configs: still sample package power / clock beside the headline step (A/B runs)")
     return ap.parse_args()
 
 
@@ -85,6 +87,8 @@ def self_launch(args) -> int:
         cmd.append("--no-extra-configs")
     if args.no_class_rows:
         cmd.append("--no-class-rows")
+    if args.power:
+        cmd.append("--power")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -198,6 +202,7 @@ def power_sample(step, sync, seconds: float = 2.5):
             step()
         sync()
         n += 20
+    burst_s = time.perf_counter() - t0
     stop.set()
     th.join(timeout=15)
     busy = [x for x in samples if x[0] > 0.5 * max(y[0] for y in samples)] if samples else []
@@ -205,7 +210,8 @@ def power_sample(step, sync, seconds: float = 2.5):
         return None
     med = lambda v: sorted(v)[len(v) // 2]
     return {"what": "rocm-smi polled beside an untimed burst of the headline step (samples above half the maximum power)",
-            "steps": n, "samples": len(busy),
+            "steps": n, "samples": len(busy), "burst_ms_per_step": round(burst_s / n * 1e3, 4),
+            "joules_per_step": round(med([x[0] for x in busy]) * burst_s / n, 3),
             "package_watts": {"median": med([x[0] for x in busy]), "min": min(x[0] for x in busy), "max": max(x[0] for x in busy)},
             "sclk_mhz": {"median": med([x[1] for x in busy]), "min": min(x[1] for x in busy), "max": max(x[1] for x in busy)},
             "cap_watts": busy[0][2], "nominal_sclk_mhz": 2400}
@@ -519,10 +525,13 @@ def run(args):
                 "e2e_frac": round(v2 / world * f2 / 1e12 / MFMA_PEAK_TFLOPS, 4),
                 "rel_l2_vs_all_rows": float(f"{rel:.3e}")}
         if world == 1:
-            if not args.no_extra_configs and not force_comm:
+            if (not args.no_extra_configs or args.power) and not force_comm:
+                row0_prev = os.environ.get("HG_LAST_BLOCK_ROW0")
                 os.environ["HG_LAST_BLOCK_ROW0"] = "0"
-                pw = power_sample(step, lambda: torch.cuda.synchronize(dev))
-                os.environ["HG_LAST_BLOCK_ROW0"] = "1"
+                try:
+                    pw = power_sample(step, lambda: torch.cuda.synchronize(dev))
+                finally:
+                    os.environ["HG_LAST_BLOCK_ROW0"] = "1" if row0_prev is None else row0_prev
                 if pw is not None:
                     pw["mfma_peak_at_sustained_clock_tflops"] = round(MFMA_PEAK_TFLOPS * pw["sclk_mhz"]["median"] / 2400.0, 1)
                     pw["e2e_frac_of_that"] = round(line["roofline"]["e2e_tflops"] / pw["mfma_peak_at_sustained_clock_tflops"], 4)

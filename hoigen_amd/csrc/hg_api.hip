@@ -511,8 +511,8 @@ hipError_t gemm(hg_ctx* c, int epi, const GemmArgs& g, hipStream_t s) {
 // kernels (c_proj 286 = 286 us, out_proj 160 vs 125 us; DESIGN.md 4 "Round 3"), and it makes a row's bits depend on where its
 // tile falls in the launch (the K loop of some tiles is cut in two).
 int streamk(hg_ctx* c, int epi, GemmArgs& g, bool force = false) {
-    static const bool on = []() { const char* e = getenv("HG_STREAMK"); return e && e[0] == '1'; }();
-    if (!(on || force) || !gemm_streamk_shape(epi, g)) return HG_OK;
+    static const int on = []() { const char* e = getenv("HG_STREAMK"); return e ? atoi(e) : 0; }();      // 2: K >= 2048 only (c_proj)
+    if (!((on == 1 || (on == 2 && g.K >= 2048)) || force) || !gemm_streamk_shape(epi, g)) return HG_OK;
     int n_cu = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) n_cu = prop.multiProcessorCount;
