@@ -9,7 +9,7 @@ on a side stream = BASELINE.json configs[4] at N = 8).
 
 A step = one pass of ``encode_image`` over one batch of 256 synthetic N(0,1) crops already resident in HBM.
 Rank 0 prints ONE JSON line.  Weights are the seeded synthetic ViT-B/16 of hoigen_amd.synth (no checkpoint is
-reachable offline).  `value` is measured with every row of every block computed (HG_LAST_BLOCK_ROW0=0).
+reachable offline).  `value` is measured with every row of every block computed (option last_block_row0 = 0).
 
 Extra objects on the line:
   roofline         the kernel with the largest share of the step (found by timing every GEMM / attention launch of
@@ -434,7 +434,7 @@ def run(args):
         per_step = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
         return dt, per_step, recs, out
 
-    os.environ["HG_LAST_BLOCK_ROW0"] = "0"       # headline: every row of every block (read per call by the library)
+    model.visual.set_option("last_block_row0", 0)       # headline: every row of every block (hg_set_option on this context)
     for _ in range(args.warmup):
         step()
     # two more untimed steps with every GEMM / attention launch bracketed by events: the per-kernel table, and which
@@ -457,7 +457,7 @@ def run(args):
     if args.no_class_rows:
         dt2, rel = dt, 0.0
     else:
-        os.environ["HG_LAST_BLOCK_ROW0"] = "1"
+        model.visual.set_option("last_block_row0", 1)
         for _ in range(args.warmup):
             step()
         dt2, per_step2, _, out2 = timed_region()
@@ -495,7 +495,7 @@ def run(args):
             "config": {"workload": "CLIP ViT-B/16 union-region encode (encode_image), 224x224 crops, "
                                    f"batch {args.batch} per GPU, synthetic N(0,1) crops + seeded synthetic weights "
                                    "(BASELINE.json configs[1]" + ("; configs[4] at 8 GPUs: 2048 crops per step" if world > 1 else "") + ")",
-                       "last_block": "all rows (HG_LAST_BLOCK_ROW0=0)",
+                       "last_block": "all rows (option last_block_row0 = 0)",
                        "flops_per_crop_executed": round(FLOPS_PER_CROP / 1e9, 3),
                        "batch_per_gpu": args.batch, "global_batch": world * args.batch,
                        "parallelism": f"dp{world}" + (f" + in-place all_gather[{world}x{args.batch}x512 f32] per step on a side stream" if (world > 1 or force_comm) else "")},
@@ -526,12 +526,11 @@ def run(args):
                 "rel_l2_vs_all_rows": float(f"{rel:.3e}")}
         if world == 1:
             if (not args.no_extra_configs or args.power) and not force_comm:
-                row0_prev = os.environ.get("HG_LAST_BLOCK_ROW0")
-                os.environ["HG_LAST_BLOCK_ROW0"] = "0"
+                model.visual.set_option("last_block_row0", 0)
                 try:
                     pw = power_sample(step, lambda: torch.cuda.synchronize(dev))
                 finally:
-                    os.environ["HG_LAST_BLOCK_ROW0"] = "1" if row0_prev is None else row0_prev
+                    model.visual.set_option("last_block_row0", 1)
                 if pw is not None:
                     pw["mfma_peak_at_sustained_clock_tflops"] = round(MFMA_PEAK_TFLOPS * pw["sclk_mhz"]["median"] / 2400.0, 1)
                     pw["e2e_frac_of_that"] = round(line["roofline"]["e2e_tflops"] / pw["mfma_peak_at_sustained_clock_tflops"], 4)
@@ -540,9 +539,7 @@ def run(args):
             if with_cpu:
                 line["cpu_baseline"] = cpu_baseline()
             if not args.no_extra_configs:
-                os.environ["HG_LAST_BLOCK_ROW0"] = "0"
-                line["variant_c"] = variant_c(dev, crops, ms_per_step)
-                os.environ["HG_LAST_BLOCK_ROW0"] = "1"
+                line["variant_c"] = variant_c(dev, crops, ms_per_step)      # (its own model; variant C always runs every row)
                 line["config3"] = config3(model, dev, with_cpu)
                 line["config4"] = config4(dev, with_cpu)
         print(json.dumps(line), flush=True)

@@ -120,6 +120,8 @@ SIGNATURES = {
     "hg_cache_logits": (_I, [_P, _I, _P, _I, _P, _P]),
     "hg_preprocess_crops": (_I, [_P, _P, _I, _I, _P, _I, _I, _I, C.c_uint32, _P, _P, _P]),
     "hg_workspace_bytes": (_I, [_P, C.POINTER(C.c_uint64)]),
+    "hg_set_option": (_I, [_P, C.c_char_p, _I]),
+    "hg_get_option": (_I, [_P, C.c_char_p, C.POINTER(C.c_int32)]),
     "hg_test_gemm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "hg_test_gemm_ln": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hg_test_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),

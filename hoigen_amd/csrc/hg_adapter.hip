@@ -646,18 +646,19 @@ __global__ __launch_bounds__(F == 2 ? 512 : 256) void adapter_decoder_mfma(const
 }
 
 bool adapter_decoder_mfma_ok(const AdapterDev& ad, bool priors, int L, int N);
-static bool decoder_mfma_on() {
-    static const bool on = []() { const char* e = getenv("HG_ADAPTER_MFMA"); return !(e && e[0] == '0'); }();
-    return on;
-}
-// down_proj inside the decoder kernel: the MFMA path with 32 tokens per wave and at least six waves (L >= 161)
+// down_proj inside the decoder kernel: the MFMA path (32 tokens per wave) with at least six waves (L >= 161); shorter sequences
+// run down_proj as its own GEMM
 bool adapter_decoder_fused_down_ok(const AdapterDev& ad, bool priors, int L, int N) {
-    static const bool tiles4 = []() { const char* e = getenv("HG_ADAPTER_TILES"); return e && atoi(e) == 4; }();
-    static const bool off = []() { const char* e = getenv("HG_ADAPTER_DOWN_FUSE"); return e && e[0] == '0'; }();
-    return !off && !tiles4 && adapter_decoder_mfma_ok(ad, priors, L, N) && 64 * ((L + 31) / 32) >= 384;
+    return adapter_decoder_mfma_ok(ad, priors, L, N) && 64 * ((L + 31) / 32) >= 384;
 }
+// the MFMA decoder serves sequences of at most NKMAX tokens and at most 32 prior tokens; anything else runs the fp32
+// one-lane-per-token kernels below (in -DHG_EXPERIMENTS builds HG_ADAPTER_MFMA=0 forces those for A/B timing)
 bool adapter_decoder_mfma_ok(const AdapterDev& ad, bool priors, int L, int N) {
-    return decoder_mfma_on() && ad.w16[priors ? 0 : 1][0] && L <= NKMAX && (priors ? N <= 32 : true);
+#ifdef HG_EXPERIMENTS
+    static const bool on = []() { const char* e = getenv("HG_ADAPTER_MFMA"); return !(e && e[0] == '0'); }();
+    if (!on) return false;
+#endif
+    return ad.w16[priors ? 0 : 1][0] && L <= NKMAX && (priors ? N <= 32 : true);
 }
 
 // down32 [M,128] fp32 (cols 0..63 = relu(down_proj(x))) -> out16 [M,64] fp16 = decoder layer output
@@ -682,10 +683,8 @@ hipError_t launch_adapter_decoder(const float* down32, const AdapterDev& ad, con
         static bool attr_set_d[HG_MAX_DEVICES] = {};
         bool& attr_set = attr_set_d[current_device_index()];
         if (!attr_set) {
-            const void* fns[6] = {reinterpret_cast<const void*>(&adapter_decoder_mfma<true, 2, false>),
+            const void* fns[4] = {reinterpret_cast<const void*>(&adapter_decoder_mfma<true, 2, false>),
                                   reinterpret_cast<const void*>(&adapter_decoder_mfma<false, 2, false>),
-                                  reinterpret_cast<const void*>(&adapter_decoder_mfma<true, 4, false>),
-                                  reinterpret_cast<const void*>(&adapter_decoder_mfma<false, 4, false>),
                                   reinterpret_cast<const void*>(&adapter_decoder_mfma<true, 2, true>),
                                   reinterpret_cast<const void*>(&adapter_decoder_mfma<false, 2, true>)};
             for (const void* fn : fns) {
@@ -694,24 +693,23 @@ hipError_t launch_adapter_decoder(const float* down32, const AdapterDev& ad, con
             }
             attr_set = true;
         }
-        // 16 F tokens per wave: F = 2 (seven waves at L = 197: prior 39 -> 30 us, self 67 -> 46 us per layer at B = 256; thirteen
-        // waves of 16 tokens: 37 / 46 us) unless HG_ADAPTER_TILES = 4 (four waves)
-        static const int tiles = []() { const char* e = getenv("HG_ADAPTER_TILES"); return e && atoi(e) == 4 ? 4 : 2; }();
+        // 16 F tokens per wave, F = 2: seven waves at L = 197 (prior 30 us, self 46 us per layer at B = 256; four waves of 64
+        // tokens took 39 / 67 us, thirteen of 16 tokens 37 / 46 us)
+        constexpr int tiles = 2;
         const int nkeys = priors ? N : L;
         const unsigned threads = 64u * (unsigned)((L + 16 * tiles - 1) / (16 * tiles));
 #define HG_DEC_LAUNCH(SELF_, F_)                                                                                                     \
     hipLaunchKernelGGL((adapter_decoder_mfma<SELF_, F_, false>), dim3(B), dim3(threads), lds, s, down32, 128, Wd, priors, mask, L, \
                        nkeys, out16, chain32, ld16, F, DDv)
         if (dn) {      // down_proj fused: 32 tokens per wave, >= 384 threads (adapter_decoder_fused_down_ok)
-            if (tiles != 2 || threads < 384 || !dn->x16 || dn->K % 128 || dn->K < 256 || dn->ldx % 8) return hipErrorInvalidValue;
+            if (threads < 384 || !dn->x16 || dn->K % 128 || dn->K < 256 || dn->ldx % 8) return hipErrorInvalidValue;
             if (priors)
                 hipLaunchKernelGGL((adapter_decoder_mfma<false, 2, true>), dim3(B), dim3(threads), lds, s, down32, 128, Wd, priors, mask, L,
                                    nkeys, out16, chain32, ld16, F, DDv);
             else
                 hipLaunchKernelGGL((adapter_decoder_mfma<true, 2, true>), dim3(B), dim3(threads), lds, s, down32, 128, Wd, priors, mask, L,
                                    nkeys, out16, chain32, ld16, F, DDv);
-        } else if (tiles == 2) { if (priors) HG_DEC_LAUNCH(false, 2); else HG_DEC_LAUNCH(true, 2); }
-        else { if (priors) HG_DEC_LAUNCH(false, 4); else HG_DEC_LAUNCH(true, 4); }
+        } else { if (priors) HG_DEC_LAUNCH(false, 2); else HG_DEC_LAUNCH(true, 2); }
 #undef HG_DEC_LAUNCH
         return hipGetLastError();
     }

@@ -48,9 +48,6 @@ struct AdapterW {
     half_t* up_w = nullptr;    // [D, 64]
     float* up_b = nullptr;
     float* scale = nullptr;
-    // K-concatenated out-proj of the block this adapter sits in: [W_out | scale * W_up] ([D, D + 64]) and b_out + scale * b_up
-    half_t* wk_out = nullptr;
-    float* bk_out = nullptr;
     // The adapter folded into the block's GEMMs altogether (hg_elem.hip adapter_q_kernel): a = Q e with e = the last decoder
     // layer's normalised output; [0] = prior path (last layer of the mhsa_layers chain), [1] = self path (mhsa)
     struct Fold {
@@ -93,8 +90,6 @@ struct Vae {
     half_t *e_w0 = nullptr, *e_wml = nullptr, *g_w0 = nullptr, *g_w2 = nullptr;
     float *e_b0 = nullptr, *e_bml = nullptr, *g_b0 = nullptr, *g_b2 = nullptr;
     // the same stacked mean | log_var operand with its rows interleaved in blocks of 128 (EPI_VAE_REPARAM_F32)
-    half_t* e_wml_i = nullptr;
-    float* e_bml_i = nullptr;
     std::vector<void*> owned;
 };
 
@@ -126,10 +121,15 @@ struct hg_ctx {
     Cache cache[HG_MAX_CACHE_SLOTS];
     // workspace (grow-only)
     Buf x, h, qkv, att, fc, head16, tok32, small, i32, ad32, ad16, adkv, mr, mu, muc, stats, pre, pretab, cx, ca, ch, cf, cq;
-    Buf skws, skfl;      // stream-K workspace + flags of the residual GEMMs (GemmArgs::sk_ws); one launch at a time per context
     int max_chunk_img = 256;
     int max_chunk_txt = 640;
     int max_chunk_rows = 32768;
+    // behaviour options: hg_set_option; the environment (HG_LAST_BLOCK_ROW0, HG_LN_FUSE, HG_ADAPTER_FUSE, HG_ADAPTER_FOLD,
+    // HG_CHUNK_ROWS) only gives their values at hg_create - nothing on the call path reads the environment
+    int opt_row0 = 1;            // last block of a tower without token outputs on the one row that leaves it
+    int opt_ln_fuse = 1;         // LayerNorm folded into the GEMMs where the shapes allow
+    int opt_adapter_fuse = 1;    // ... also behind the instance adapters (variant C)
+    int opt_adapter_fold = 1;    // adapter folded into the block's own QKV / out-proj GEMMs (0: separate up_proj GEMM)
     // sticky device->host flag (host-mapped): set by clamp_eot when a caller-supplied text truncation was shorter than
     // max(EOT)+1 (a stale host memo); reported as HG_ERR_INVALID by the next text call
     int32_t* eot_flag = nullptr;
@@ -447,12 +447,6 @@ int load_adapters(hg_ctx* c, const hg_adapter_weights* src, int layers) {
             rc = load_decoder_layer(c, own, s.extra_prior_layers[z], d, a.extra[z].dl, a.extra[z].w16);
             if (rc) return rc;
         }
-        if ((int)v.blocks.size() > i && v.blocks[i].w_out) {
-            keep_first(rc, dev_alloc(c, own, (size_t)D * (D + d) * 2, (void**)&a.wk_out));
-            keep_first(rc, dev_alloc(c, own, (size_t)D * 4, (void**)&a.bk_out));
-            if (rc) return rc;
-            HG_HIP(launch_concat_upproj(v.blocks[i].w_out, v.blocks[i].b_out, a.up_w, a.up_b, a.scale, a.wk_out, a.bk_out, D, D, d, 0));
-        }
         if ((int)v.blocks.size() > i && v.blocks[i].w_out && v.blocks[i].wf_qkv) {
             std::vector<void*> sc;
             float* q32 = nullptr;
@@ -506,24 +500,6 @@ hipError_t gemm(hg_ctx* c, int epi, const GemmArgs& g, hipStream_t s) {
     return launch_gemm(epi, g, s);
 }
 
-// Stream-K for the residual GEMMs whose 256x256 tiles fill the chip unevenly (N = 768 at batch 256: 2.31 rounds): hands the
-// context's workspace to the launch when the shape qualifies.  Opt-in (HG_STREAMK=1): measured, it only ties the whole-tile
-// kernels (c_proj 286 = 286 us, out_proj 160 vs 125 us; DESIGN.md 4 "Round 3"), and it makes a row's bits depend on where its
-// tile falls in the launch (the K loop of some tiles is cut in two).
-int streamk(hg_ctx* c, int epi, GemmArgs& g, bool force = false) {
-    static const int on = []() { const char* e = getenv("HG_STREAMK"); return e ? atoi(e) : 0; }();      // 2: K >= 2048 only (c_proj)
-    if (!((on == 1 || (on == 2 && g.K >= 2048)) || force) || !gemm_streamk_shape(epi, g)) return HG_OK;
-    int n_cu = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) n_cu = prop.multiProcessorCount;
-    int rc = ensure(c, c->skws, (size_t)n_cu * GEMM_SK_WS_BYTES);
-    if (!rc) rc = ensure(c, c->skfl, (size_t)n_cu * GEMM_SK_FLAG_BYTES);      // (ensure() zeroes new memory: flags start at 0)
-    if (rc) return rc;
-    g.sk_ws = (float*)c->skws.p;
-    g.sk_flags = (int*)c->skfl.p;
-    return HG_OK;
-}
-
 hipError_t attention(hg_ctx* c, const half_t* qkv, half_t* out, int n_seq, int L, int heads, bool causal, hipStream_t s,
                      int ldo = 0) {
     ProfScope ps(c, s, HG_PROF_ATTENTION, n_seq, L, heads);
@@ -540,10 +516,7 @@ struct AdapterCall {
 
 // `fused`: LayerNorm folding is on - the stream's centred fp16 copy (c->h), its centre (c->muc) and the folding
 // statistics are current; the adapter consumes the copy and its up_proj re-emits all three for the updated stream
-// `kcat`: the adapter's update of the fp32 stream is left to the block's K-concatenated out-proj ([att | d] x [W_out | scale W_up]):
-// the decoder output d goes into columns D .. D+63 of the attention output buffer (row stride D + 64) and up_proj only refreshes
-// the centred fp16 copy + statistics that ln_1 needs (EPI_X16_SCALE_LN: no fp32 traffic at all)
-// `kcat` = 2: the adapter folded into the block's GEMMs altogether - nothing but down_proj and the decoder runs here; the
+// `kcat` = 2 (0 = off): the adapter folded into the block's GEMMs altogether - nothing but down_proj and the decoder runs here; the
 // centred fp16 copy of the stream is expected in columns 0..D-1 of c->att (row stride D + 64), the decoder writes e beside it and
 // turns c->mr into the statistics of x + a; the block's QKV GEMM then takes [x16 | e] x [W'_qkv | W'_qkv Q]
 int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const AdapterCall& ac, hipStream_t s, bool fused,
@@ -552,12 +525,11 @@ int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const Ada
 // LayerNorm folded into the GEMMs: the residual GEMMs (out-proj, c_proj) also emit the fp16 copy of the updated
 // rows and per-row partial statistics; the consuming GEMMs (QKV, c_fc) read that copy and apply mean / rstd in
 // their epilogue.  Used when every GEMM of the block is eligible for the ring kernels and no adapter rewrites
-// the stream between the residual GEMM and its LayerNorm.  HG_LN_FUSE=0 selects the separate-LayerNorm path.
+// the stream between the residual GEMM and its LayerNorm.  Option ln_fuse = 0 selects the separate-LayerNorm path.
 bool ln_fuse_ok(hg_ctx* c, int M, int D) {
     // Whenever the shapes are eligible (M >= 512): one arithmetic for every batch size keeps a row's result
-    // independent of the batch it is in.  HG_LN_FUSE=0 selects the separate-LayerNorm path.
-    const char* e = getenv("HG_LN_FUSE");
-    if (e && e[0] == '0') return false;
+    // independent of the batch it is in.  Option ln_fuse = 0 selects the separate-LayerNorm path.
+    if (!c->opt_ln_fuse) return false;
     if (D % 256) return false;
     GemmArgs g{};
     float dummy = 0.f;
@@ -578,7 +550,7 @@ bool ln_fuse_ok(hg_ctx* c, int M, int D) {
 // token of the text tower) or row 0 when sel is null (the class token of the vision tower) - so the LAST block
 // computes K and V for all rows but Q, attention, out-proj and the MLP for those n_seq rows only (a dense
 // [n_seq, D] stream, returned through *row0_out); all other rows of that block never reach any output.
-// HG_LAST_BLOCK_ROW0=0 runs the last block on every row like the others.
+// Option last_block_row0 = 0 runs the last block on every row like the others.
 // `pre_w` / `pre_b` (vision tower): the LayerNorm in front of the first block (ln_pre) has NOT been applied yet; it runs
 // here, fused with the first block's folding statistics when folding is on - and, with `pre_pos` / `pre_cls`, with the class
 // rows and the positional embedding the patch GEMM left out (clipnet/model.py:223-225 in one pass over the rows)
@@ -587,8 +559,7 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
                const float** row0_out = nullptr, const int32_t* sel = nullptr, const float* pre_w = nullptr,
                const float* pre_b = nullptr, const float* pre_pos = nullptr, const float* pre_cls = nullptr) {
     const int M = n_seq * L;
-    const char* row0_e = getenv("HG_LAST_BLOCK_ROW0");      // read per call: the tests switch it
-    const bool row0_env = !(row0_e && row0_e[0] == '0');
+    const bool row0_env = c->opt_row0 != 0;
     if (row0_out) *row0_out = nullptr;
     float* x = (float*)c->x.p;
     half_t* h = (half_t*)c->h.p;
@@ -597,10 +568,9 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
     half_t* fc = (half_t*)c->fc.p;
     const bool adapters = ac && ac->enabled;
     // With adapters the folding survives when the adapter's up_proj can re-emit the fp16 copy and statistics
-    // (EPI_SCALE_RESID_LN_F32, duo kernel): HG_ADAPTER_FUSE=0 selects the separate path (fp32 -> fp16 copy of the stream
+    // (EPI_SCALE_RESID_LN_F32, duo kernel): option adapter_fuse = 0 selects the separate path (fp32 -> fp16 copy of the stream
     // per adapter, two LayerNorm kernels per block)
-    const char* af_e = getenv("HG_ADAPTER_FUSE");
-    const bool adapter_fuse_on = !(af_e && af_e[0] == '0');
+    const bool adapter_fuse_on = c->opt_adapter_fuse != 0;
     bool fuse = ln_fold && ln_fuse_ok(c, M, D);
     if (fuse && adapters) {
         GemmArgs u{};
@@ -609,11 +579,11 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         u.M = M; u.N = D; u.ldc = D; u.K = 64; u.lda = 64;
         fuse = adapter_fuse_on && gemm_duo_ok(EPI_SCALE_RESID_LN_F32, u);
     }
-    // How the adapter of block i reaches the stream (HG_ADAPTER_KCAT, default 2):
-    //   0  up_proj GEMM with a scaled-residual epilogue on the fp32 stream (+ fp16 copy + statistics)
-    //   1  the update rides in the block's K-concatenated out-proj; up_proj only refreshes the fp16 copy + statistics for ln_1
-    //   2  no up_proj at all: QKV takes [x16 | e] as well, ln_1's statistics come from the decoder (run_adapter)
-    static const int kcat_env = []() { const char* e = getenv("HG_ADAPTER_KCAT"); return e ? atoi(e) : 2; }();
+    // How the adapter of block i reaches the stream:
+    //   2  (default, option adapter_fold = 1, when the shapes allow) folded into the block's own GEMMs: QKV takes [x16 | e], out-proj
+    //      [att | e], ln_1's statistics come from the decoder kernel (run_adapter) - no up_proj launch at all
+    //   0  up_proj GEMM with a scaled-residual epilogue on the fp32 stream (+ fp16 copy + statistics when folding LayerNorm)
+    const int kcat_env = c->opt_adapter_fold ? 2 : 0;
     std::vector<int> kmode(blocks.size(), 0);
     bool any_k2 = false;
     if (adapters && fuse)
@@ -621,7 +591,6 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
             if (c->vit.adapters.size() <= i || !c->vit.adapters[i].present) continue;
             const AdapterW& aw = c->vit.adapters[i];
             if (row0_out && row0_env && i + 1 == blocks.size()) continue;
-            if (kcat_env >= 1 && aw.wk_out) kmode[i] = 1;
             if (kcat_env >= 2 && aw.fold[ac->priors ? 0 : 1].wq_cat) {
                 AdapterDev ad{};
                 for (int k = 0; k < 2; ++k) ad.w16[k][0] = aw.w16[k][0];
@@ -660,7 +629,7 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         stats = (float*)c->stats.p;
         if (pre_w) HG_HIP(launch_layernorm_rowstats(x, pre_w, pre_b, h_of(0), mr, mu, muc, M, D, s, pre_pos, pre_cls, L, ldh_of(0)));
         else {
-            if (kmode.size() && kmode[0] == 2) kmode[0] = 1;      // rowstats_cast writes dense rows
+            if (kmode.size() && kmode[0] == 2) kmode[0] = 0;      // rowstats_cast writes dense rows
             HG_HIP(launch_rowstats_cast(x, h, mr, mu, M, D, s, muc));
         }
     } else if (pre_w) {
@@ -731,18 +700,14 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         HG_HIP(attention(c, qkv, att, n_seq, L, heads, causal, s, kcat ? D + 64 : 0));
         g = GemmArgs{};
         g.A = att; g.lda = D; g.W = b.w_out; g.bias = b.b_out; g.out = x; g.ldc = D; g.M = M; g.N = D; g.K = D;
-        if (kcat == 1) {      // x += [att | d] [W_out | scale W_up]^T + (b_out + scale b_up): the adapter's update rides along
-            g.lda = D + 64; g.K = D + 64; g.W = c->vit.adapters[i].wk_out; g.bias = c->vit.adapters[i].bk_out;
-        } else if (kcat == 2) {      // ... as [att | e] [W_out | Q]^T + b_out
+        if (kcat == 2) {      // x += [att | e] [W_out | Q]^T + b_out: the adapter's update rides along
             g.lda = D + 64; g.K = D + 64; g.W = c->vit.adapters[i].fold[ac->priors ? 0 : 1].wk_out;
         }
         if (fuse) {
             g.out2 = h; g.stats = stats; g.stats_ld = sld; g.mu = mu;
-            if (int rc = streamk(c, EPI_RESID_LN_F32, g)) return rc;
             HG_HIP(gemm(c, EPI_RESID_LN_F32, g, s));
             HG_HIP(launch_finalize_stats(stats, mr, mu, M, sld, 64, s, muc));
         } else {
-            if (int rc = streamk(c, EPI_BIAS_RESID_F32, g)) return rc;
             HG_HIP(gemm(c, EPI_BIAS_RESID_F32, g, s));
         }
         g = GemmArgs{};
@@ -759,11 +724,9 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         g.A = fc; g.lda = 4 * D; g.W = b.w_proj; g.bias = b.b_proj; g.out = x; g.ldc = D; g.M = M; g.N = D; g.K = 4 * D;
         if (fuse && i + 1 < blocks.size()) {      // the last block is followed by ln_post / ln_final on selected rows
             g.out2 = h_of(i + 1); g.ld2 = ldh_of(i + 1); g.stats = stats; g.stats_ld = sld; g.mu = mu;
-            if (int rc = streamk(c, EPI_RESID_LN_F32, g)) return rc;
             HG_HIP(gemm(c, EPI_RESID_LN_F32, g, s));
             HG_HIP(launch_finalize_stats(stats, mr, mu, M, sld, 64, s, muc));
         } else {
-            if (int rc = streamk(c, EPI_BIAS_RESID_F32, g)) return rc;
             HG_HIP(gemm(c, EPI_BIAS_RESID_F32, g, s));
         }
         if (trace) HG_HIP(launch_copy_rows(x, trace + (size_t)(i + 1) * trace_stride, n_seq, L, D, s));
@@ -822,12 +785,8 @@ int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const Ada
     const int n_chain = ac.priors ? 1 + (int)a.extra.size() : 1;
     // chained layers exist only in the MFMA decoder (one workgroup per sequence, <= 32 prior tokens): say so up front
     // instead of failing inside the launch
-    if (n_chain > 1) {
-        const char* e = getenv("HG_ADAPTER_MFMA");
-        if ((e && e[0] == '0') || ac.N > 32)
-            return fail(c, HG_ERR_INVALID, "adapter_num_layers > 1 needs the MFMA decoder path: at most 32 prior tokens (got %d) "
-                                           "and HG_ADAPTER_MFMA != 0", ac.N);
-    }
+    if (n_chain > 1 && !adapter_decoder_mfma_ok(ad, true, L, ac.N))
+        return fail(c, HG_ERR_INVALID, "adapter_num_layers > 1 needs the MFMA decoder path: at most 32 prior tokens (got %d)", ac.N);
     for (int z = 0; z < n_chain; ++z) {
         if (z > 0)
             for (int j = 0; j < 12; ++j) ad.dl[0][j] = a.extra[z - 1].dl[j];
@@ -853,14 +812,7 @@ int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const Ada
     g = GemmArgs{};
     g.A = (const half_t*)c->ad16.p; g.lda = 64; g.W = a.up_w; g.bias = a.up_b; g.pos = a.scale; g.out = x; g.ldc = D;
     g.M = M; g.N = D; g.K = 64;
-    if (fused && kcat == 1) {   // the stream gets the update in out-proj; ln_1 needs the fp16 copy + statistics of x + a now
-        const int sld = 4 * (D / 256);
-        g.A = (const half_t*)c->att.p + D; g.lda = D + 64; g.out = nullptr;
-        g.out2 = h; g.stats = (float*)c->stats.p; g.stats_ld = sld;
-        HG_HIP(gemm(c, EPI_X16_SCALE_LN, g, s));
-        HG_HIP(launch_finalize_stats((const float*)c->stats.p, (float*)c->mr.p, (float*)c->mu.p, M, sld, 64, s,
-                                     (float*)c->muc.p, true));
-    } else if (fused) {       // ... and re-emit the fp16 copy + row statistics of the updated stream for the folded ln_1
+    if (fused) {       // ... and re-emit the fp16 copy + row statistics of the updated stream for the folded ln_1
         const int sld = 4 * (D / 256);
         g.out2 = h; g.stats = (float*)c->stats.p; g.stats_ld = sld; g.mu = (const float*)c->mu.p;
         HG_HIP(gemm(c, EPI_SCALE_RESID_LN_F32, g, s));
@@ -893,11 +845,39 @@ hg_ctx* hg_create(int device) {
         if (hipHostMalloc((void**)&c->eot_flag, 64, hipHostMallocMapped) == hipSuccess && c->eot_flag) *c->eot_flag = 0;
         else c->eot_flag = nullptr;
     }
-    if (const char* e = getenv("HG_CHUNK_ROWS")) {          // tuning knob: rows per VAE / mlp_net / cache-logits chunk
-        const int v = atoi(e);
-        if (v >= 256) c->max_chunk_rows = v;
-    }
+    struct { const char* env; const char* key; } init[] = {{"HG_CHUNK_ROWS", "chunk_rows"}, {"HG_LAST_BLOCK_ROW0", "last_block_row0"},
+                                                           {"HG_LN_FUSE", "ln_fuse"}, {"HG_ADAPTER_FUSE", "adapter_fuse"},
+                                                           {"HG_ADAPTER_FOLD", "adapter_fold"}};
+    for (auto& o : init)
+        if (const char* e = getenv(o.env)) (void)hg_set_option(c, o.key, atoi(e));      // (out-of-range values are ignored)
+    c->err.clear();
     return c;
+}
+
+int hg_set_option(hg_ctx* c, const char* key, int value) {
+    if (!c || !key) return HG_ERR_INVALID;
+    const std::string k(key);
+    if (k == "chunk_rows") {          // rows per VAE / mlp_net / cache-logits chunk
+        if (value < 256) return fail(c, HG_ERR_INVALID, "chunk_rows must be >= 256");
+        c->max_chunk_rows = value;
+    } else if (k == "last_block_row0") c->opt_row0 = value != 0;
+    else if (k == "ln_fuse") c->opt_ln_fuse = value != 0;
+    else if (k == "adapter_fuse") c->opt_adapter_fuse = value != 0;
+    else if (k == "adapter_fold") c->opt_adapter_fold = value != 0;
+    else return fail(c, HG_ERR_INVALID, "unknown option '%s'", key);
+    return HG_OK;
+}
+
+int hg_get_option(hg_ctx* c, const char* key, int* value) {
+    if (!c || !key || !value) return HG_ERR_INVALID;
+    const std::string k(key);
+    if (k == "chunk_rows") *value = c->max_chunk_rows;
+    else if (k == "last_block_row0") *value = c->opt_row0;
+    else if (k == "ln_fuse") *value = c->opt_ln_fuse;
+    else if (k == "adapter_fuse") *value = c->opt_adapter_fuse;
+    else if (k == "adapter_fold") *value = c->opt_adapter_fold;
+    else return fail(c, HG_ERR_INVALID, "unknown option '%s'", key);
+    return HG_OK;
 }
 
 void hg_destroy(hg_ctx* c) {
@@ -911,8 +891,7 @@ void hg_destroy(hg_ctx* c) {
     for (auto& m : c->mlp) free_all(m.owned);
     for (auto& m : c->cache) free_all(m.owned);
     Buf* bufs[] = {&c->x, &c->h, &c->qkv, &c->att, &c->fc, &c->head16, &c->tok32, &c->small, &c->i32,
-                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq,
-                   &c->skws, &c->skfl};
+                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq};
     for (Buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
@@ -1068,10 +1047,7 @@ int hg_test_gemm_ln(hg_ctx* c, const float* a, const float* w, const float* bias
         g.pos = scale;
     }
     hipError_t e;
-    if (kernel == 4) {      // the 256x256 ring kernel with stream-K (falls back to whole tiles when the shape does not qualify)
-        if (int rc2 = streamk(c, epi, g, true)) return rc2;
-        e = gemm_ln_ok(epi, g) ? launch_gemm_ring(epi, g, s) : hipErrorInvalidValue;
-    } else if (kernel == 2) e = gemm_ln_ok(epi, g) ? launch_gemm_ring(epi, g, s) : hipErrorInvalidValue;
+    if (kernel == 2) e = gemm_ln_ok(epi, g) ? launch_gemm_ring(epi, g, s) : hipErrorInvalidValue;
     else if (kernel == 3) e = gemm_duo_ok(epi, g) ? launch_gemm_duo(epi, g, s) : hipErrorInvalidValue;
     else e = launch_gemm(epi, g, s);
     if (e != hipSuccess) return fail(c, HG_ERR_HIP, "test gemm (ln) launch failed: %s", hipGetErrorString(e));
@@ -1148,8 +1124,7 @@ int hg_profile_end(hg_ctx* c, hg_prof_rec* recs, int max_recs, int32_t* n_recs) 
 int hg_workspace_bytes(hg_ctx* c, uint64_t* bytes) {
     if (!c || !bytes) return HG_ERR_INVALID;
     Buf* bufs[] = {&c->x, &c->h, &c->qkv, &c->att, &c->fc, &c->head16, &c->tok32, &c->small, &c->i32,
-                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq,
-                   &c->skws, &c->skfl};
+                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq};
     uint64_t t = 0;
     for (Buf* b : bufs) t += b->bytes;
     *bytes = t;
@@ -1271,19 +1246,6 @@ int hg_load_vae(hg_ctx* c, int slot, const hg_vae_weights* w) {
         }
         free_all(sc);
         if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
-        // interleaved copy: rows [256b, 256b+128) = mean rows [128b, 128b+128), rows [256b+128, 256b+256) = log_var rows
-        keep_first(rc, dev_alloc(c, v.owned, (size_t)2 * v.dim * v.eh * 2, &p));
-        if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
-        v.e_wml_i = (half_t*)p;
-        keep_first(rc, dev_alloc(c, v.owned, (size_t)2 * v.dim * 4, &p));
-        if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
-        v.e_bml_i = (float*)p;
-        for (int b = 0; b < v.dim / 128; ++b)
-            for (int h = 0; h < 2; ++h) {
-                (void)hipMemcpy(v.e_wml_i + ((size_t)256 * b + 128 * h) * v.eh, v.e_wml + ((size_t)h * v.dim + 128 * b) * v.eh,
-                                (size_t)128 * v.eh * 2, hipMemcpyDeviceToDevice);
-                (void)hipMemcpy(v.e_bml_i + 256 * b + 128 * h, v.e_bml + h * v.dim + 128 * b, 128 * 4, hipMemcpyDeviceToDevice);
-            }
         v.enc = true;
     }
     if (w->gen_w0.ptr) {
@@ -1531,8 +1493,9 @@ int hg_encode_image_prior(hg_ctx* c, const float* x_nchw, const float* priors, c
 
 // ---- text tower -------------------------------------------------------------------------------------------
 // A truncation length that does not cover every EOT position (a stale host-side max(EOT)) must not gather
-// another sequence's row or read out of bounds: EOT indices are clamped into [0, Leff) on the device and a sticky
-// host-mapped flag makes the NEXT text call fail with HG_ERR_INVALID (this call cannot know without a sync).
+// another sequence's row or read out of bounds: EOT indices are clamped into [0, Leff) on the device; the same flag turns the
+// WHOLE output of that call into NaN at its end (the stale call itself is loud: launch_poison_if_flag) and, being sticky and
+// host-mapped, makes the NEXT text call fail with HG_ERR_INVALID and an explanation (this call cannot be failed without a sync).
 static int text_check_flag(hg_ctx* c) {
     if (c->eot_flag && *(volatile int32_t*)c->eot_flag) {
         *(volatile int32_t*)c->eot_flag = 0;
@@ -1585,6 +1548,7 @@ int hg_encode_text_ids(hg_ctx* c, const int32_t* ids, int T, int L, float* out, 
         rc = text_tail(c, Tc, Leff, eot, out + (size_t)t0 * t.E, s);
         if (rc) return rc;
     }
+    if (Leff < L) HG_HIP(launch_poison_if_flag(out, (size_t)T * t.E, c->eot_flag, s));
     return HG_OK;
 }
 
@@ -1616,6 +1580,7 @@ int hg_encode_text_embeds(hg_ctx* c, const float* prompts, const int32_t* eot_id
         rc = text_tail(c, Rc, Leff, eot, out + (size_t)r0 * t.E, s);
         if (rc) return rc;
     }
+    if (Leff < L) HG_HIP(launch_poison_if_flag(out, (size_t)R * t.E, c->eot_flag, s));
     return HG_OK;
 }
 
@@ -1674,20 +1639,12 @@ int hg_vae_forward(hg_ctx* c, int slot, const float* x, const float* eps, int R,
         // mean | log_var as ONE N = 2*dim GEMM whose two column halves land directly in the caller's tensors
         g = GemmArgs{};
         g.A = h1; g.lda = v.eh; g.out = mean_o; g.out_hi = lv_o; g.ldc = dim; g.M = Rc; g.N = 2 * dim; g.K = v.eh;
-        // HG_VAE_FUSE=1: reparameterise in the GEMM's epilogue (interleaved rows: a lane holds mean_j and log_var_j) when the
-        // ring kernels take the shape - one launch and 410 MB of HBM traffic less per 100 k rows, the same arithmetic bit
-        // for bit, but measured 0.5-2 % SLOWER (round 3: 1.65 vs 1.61 ms per 100 k rows): the epilogue's 56 partial-line
-        // stores per wave cost the GEMM what the HBM-speed reparam kernel costs on its own, and nothing hides them.
-        // Default: the plain stacked GEMM + the reparam kernel.
-        g.W = v.e_wml_i; g.bias = v.e_bml_i; g.pos = eps + o; g.out2 = z16; g.out3 = z ? z + o : nullptr;
-        static const bool fuse_on = []() { const char* e = getenv("HG_VAE_FUSE"); return e && e[0] == '1'; }();
-        if (fuse_on && gemm_ln_ok(EPI_VAE_REPARAM_F32, g)) {
-            HG_HIP(gemm(c, EPI_VAE_REPARAM_F32, g, s));
-        } else {
-            g.W = v.e_wml; g.bias = v.e_bml; g.pos = nullptr; g.out2 = nullptr; g.out3 = nullptr; g.n_split = dim;
-            HG_HIP(gemm(c, EPI_BIAS_F32, g, s));
-            HG_HIP(launch_reparam(mean_o, lv_o, eps + o, Rc, dim, z ? z + o : nullptr, z16, dim, s));
-        }
+        // (The reparameterisation on the accumulators of a row-interleaved mean | log_var GEMM was built and measured in round 3:
+        // bit-identical, one launch and 410 MB less per 100 k rows, 0.5-2 % SLOWER - its 56 partial-line stores per wave cost the
+        // GEMM what the HBM-speed reparam kernel costs on its own; commit 2b473ec and earlier carry it.)
+        g.W = v.e_wml; g.bias = v.e_bml; g.n_split = dim;
+        HG_HIP(gemm(c, EPI_BIAS_F32, g, s));
+        HG_HIP(launch_reparam(mean_o, lv_o, eps + o, Rc, dim, z ? z + o : nullptr, z16, dim, s));
         if (bias) {
             rc = generator_rows(c, v, z16, Rc, bias + o, s);
             if (rc) return rc;

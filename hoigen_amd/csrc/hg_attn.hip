@@ -260,7 +260,11 @@ static hipError_t launch_t(const half_t* qkv, half_t* out, int n_seq, int L, int
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    static const int mode = getenv("HG_ATTN_MODE") ? atoi(getenv("HG_ATTN_MODE")) : 0;   // read by experiment builds only
+#ifdef HG_EXPERIMENTS
+    static const int mode = getenv("HG_ATTN_MODE") ? atoi(getenv("HG_ATTN_MODE")) : 0;
+#else
+    constexpr int mode = 0;
+#endif
     hipLaunchKernelGGL((attention_kernel<CAUSAL, ROW0>), dim3(n_seq * heads), dim3(64 * nkt), lds, s, qkv, out, L, heads, nkt, q0, sel,
                        mode, ldo);
     return hipGetLastError();

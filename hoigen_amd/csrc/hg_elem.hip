@@ -244,6 +244,20 @@ hipError_t launch_clamp_eot(const int32_t* in, int n, int Leff, int32_t* out, in
     return hipGetLastError();
 }
 
+// A truncation length that did not cover every EOT row (flag set by clamp_eot_kernel earlier in the same call): the call's
+// whole output becomes NaN - the stale call itself is loud, not only the next one (it cannot be failed without a sync)
+__global__ __launch_bounds__(256) void poison_if_flag_kernel(float* out, size_t n, const int32_t* flag) {
+    if (*(const volatile int32_t*)flag == 0) return;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = __builtin_nanf("");
+}
+hipError_t launch_poison_if_flag(float* out, size_t n, const int32_t* flag, hipStream_t s) {
+    if (n == 0 || !flag) return hipSuccess;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(poison_if_flag_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, n, flag);
+    return hipGetLastError();
+}
+
 // ---- dtype conversion / transposition (weight loading) ------------------------------------------------
 // dtype conversions, HBM-bound: 8 elements per lane (2 x 16-byte loads -> one 16-byte store, and back) when the
 // pointers are 16-byte aligned, scalar otherwise and for the tail

@@ -209,7 +209,11 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
         attr_set = true;
     }
+#ifdef HG_EXPERIMENTS
     static const bool deep_on = []() { const char* e = getenv("HG_GEMM_DEEP"); return e ? atoi(e) != 0 : true; }();
+#else
+    constexpr bool deep_on = true;
+#endif
     const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
     if (deep_on && grid <= n_cu && a.K / BK >= 4)
         hipLaunchKernelGGL((gemm_nt_128x128<EPI, 4>), dim3(grid), dim3(256), GEMM_LDS_DEEP, s, a);
@@ -219,24 +223,24 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_gemm(int epi, const GemmArgs& a, hipStream_t s) {
-    static const int force_simple = []() {
-        const char* e = getenv("HG_GEMM");
-        return (e && e[0] == 's') ? 1 : 0;      // HG_GEMM=simple: A/B against the 128x128 kernel
-    }();
-    if (a.M <= 0) return hipSuccess;
-    // HG_DUO: 0 = never; 1 (default) = the plain residual GEMMs (text tower, the vision tower's last c_proj) run on the
-    // two-workgroups-per-CU kernel (117 / 293 us against 147 / 305 us of the ring kernels at M = 50432); 2 = every
-    // epilogue it implements except the LayerNorm-emitting residual (ring2 and duo tie there); 3 = that one as well
+    // Which kernel runs a shape is fixed here; -DHG_EXPERIMENTS builds can override it for A/B timing: HG_GEMM=simple (the
+    // 128x128 kernel everywhere), HG_DUO = 0 never / 1 plain residual GEMMs (the default) / 2 every epilogue the duo kernel
+    // implements except the LayerNorm-emitting residual / 3 that one as well
+#ifdef HG_EXPERIMENTS
+    static const int force_simple = []() { const char* e = getenv("HG_GEMM"); return (e && e[0] == 's') ? 1 : 0; }();
     static const int duo = []() { const char* e = getenv("HG_DUO"); return e ? atoi(e) : 1; }();
-    if (epi == EPI_SCALE_RESID_LN_F32 || epi == EPI_X16_SCALE_LN)
-        return gemm_duo_ok(epi, a) ? launch_gemm_duo(epi, a, s) : hipErrorInvalidValue;
+#else
+    constexpr int force_simple = 0, duo = 1;
+#endif
+    if (a.M <= 0) return hipSuccess;
+    // the plain residual GEMMs (text tower, the vision tower's last c_proj) run on the two-workgroups-per-CU kernel (117 / 293 us
+    // against 147 / 305 us of the ring kernels at M = 50432)
+    if (epi == EPI_SCALE_RESID_LN_F32) return gemm_duo_ok(epi, a) ? launch_gemm_duo(epi, a, s) : hipErrorInvalidValue;
     if (epi == EPI_MU_BIAS_RELU_F32) return launch_gemm_simple(epi, a, s);
     const bool own_ld2 = a.ld2 && a.ld2 != a.ldc;      // fp16 copy with its own row stride: the ring kernels only
-    const bool use_duo = !own_ld2 && !(a.sk_ws && gemm_streamk_shape(epi, a)) &&
-                         (duo >= 3 || (duo == 2 && epi != EPI_RESID_LN_F32) || (duo == 1 && epi == EPI_BIAS_RESID_F32));
+    const bool use_duo = !own_ld2 && (duo >= 3 || (duo == 2 && epi != EPI_RESID_LN_F32) || (duo == 1 && epi == EPI_BIAS_RESID_F32));
     if (!force_simple && use_duo && gemm_duo_ok(epi, a)) return launch_gemm_duo(epi, a, s);
-    const bool ln = (epi == EPI_LN_BIAS_F16 || epi == EPI_LN_BIAS_QGELU_F16 || epi == EPI_RESID_LN_F32 ||
-                     epi == EPI_VAE_REPARAM_F32);
+    const bool ln = (epi == EPI_LN_BIAS_F16 || epi == EPI_LN_BIAS_QGELU_F16 || epi == EPI_RESID_LN_F32);
     if (ln) return gemm_ln_ok(epi, a) ? launch_gemm_ring(epi, a, s) : hipErrorInvalidValue;   // ring kernels only
     if (!force_simple && gemm_ring_ok(a)) return launch_gemm_ring(epi, a, s);
     return launch_gemm_simple(epi, a, s);

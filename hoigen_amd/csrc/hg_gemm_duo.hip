@@ -54,8 +54,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo(const GemmArgs p, const int t
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BM = 128, BK = 64;
     constexpr int A_BYTES = 16384, W_BYTES = 32768;
-    constexpr bool X16 = (EPI == EPI_X16_SCALE_LN);                // the update goes into the centred fp16 copy only (in place)
-    constexpr bool SCALED = (EPI == EPI_SCALE_RESID_LN_F32 || X16); // update multiplied by pos[n] (adapter up_proj)
+    constexpr bool SCALED = (EPI == EPI_SCALE_RESID_LN_F32);       // update multiplied by pos[n] (adapter up_proj)
     constexpr bool RLN = (EPI == EPI_RESID_LN_F32 || SCALED);
     constexpr bool RESID = (EPI == EPI_BIAS_RESID_F32 || RLN);
     constexpr bool F16OUT = (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_BIAS_RELU_F16);
@@ -260,63 +259,32 @@ __global__ __launch_bounds__(256, 2) void gemm_duo(const GemmArgs p, const int t
             for (int f = 0; f < 4; ++f) {
                 const int mc = mrow[f] < p.M ? mrow[f] : p.M - 1;
                 ro[f] = (size_t)mc * p.ldc + nw;
-                if constexpr (RLN) muv[f] = X16 ? 0.f : p.mu[mc];      // X16: the values are centred already
+                if constexpr (RLN) muv[f] = p.mu[mc];
             }
             // residual rows (+ bias) through a register pipeline DEPTH column groups deep: the fragment registers are
             // dead here, and a shallower pipeline exposes one HBM round trip per group (8 per tile: measured 53 k cycles
             // per tile against 13 k for the whole K loop of out_proj)
             // 5 spills with the LayerNorm extras (row sums, centres), 4 with the column scale of the adapter epilogue on top
-            constexpr int DEPTH = RLN ? (SCALED ? (X16 ? 4 : 3) : 4) : 5;
+            constexpr int DEPTH = RLN ? (SCALED ? 3 : 4) : 5;
             f32x4 xr[8][4], bvv[8], scv[SCALED ? 8 : 1];
-            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-            u32x4_t xh[X16 ? 8 : 1][2];          // X16: the old copy in its stored layout (row tiles 2pr, 2pr+1 paired, see below)
-            size_t ro16[2];
-            if constexpr (X16) {
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    const int m = m0 + wm * 64 + pr * 32 + (lane & 15) + ((q & 1) ? 16 : 0);
-                    ro16[pr] = (size_t)(m < p.M ? m : p.M - 1) * p.ldc + n0 + wn * 128 + 4 * (q & ~1);
-                }
-            }
             const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
             auto fetch = [&](auto GG) {
                 constexpr int gg = decltype(GG)::value;
-                if constexpr (X16) {
 #pragma unroll
-                    for (int pr = 0; pr < 2; ++pr) xh[gg][pr] = *reinterpret_cast<const u32x4_t*>(p.out2 + ro16[pr] + gg * 16);
-                } else {
-#pragma unroll
-                    for (int f = 0; f < 4; ++f) xr[gg][f] = *reinterpret_cast<const f32x4*>(xo + ro[f] + gg * 16);
-                }
+                for (int f = 0; f < 4; ++f) xr[gg][f] = *reinterpret_cast<const f32x4*>(xo + ro[f] + gg * 16);
                 bvv[gg] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nw + gg * 16) : z4;
                 if constexpr (SCALED) scv[gg] = *reinterpret_cast<const f32x4*>(p.pos + nw + gg * 16);
             };
             float sum[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
             auto consume = [&](auto GG) {
                 constexpr int gg = decltype(GG)::value;
-                if constexpr (X16) {      // undo the v_permlane16_swap pairing of the stored copy: rows 2pr and 2pr+1 of this lane
-                    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-#pragma unroll
-                    for (int pr = 0; pr < 2; ++pr) {
-                        const auto s0 = __builtin_amdgcn_permlane16_swap(xh[gg][pr][0], xh[gg][pr][2], false, false);
-                        const auto s1 = __builtin_amdgcn_permlane16_swap(xh[gg][pr][1], xh[gg][pr][3], false, false);
-                        const half4 hx = __builtin_bit_cast(half4, u32x2_t{(unsigned)s0[0], (unsigned)s1[0]});
-                        const half4 hy = __builtin_bit_cast(half4, u32x2_t{(unsigned)s0[1], (unsigned)s1[1]});
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            xr[gg][2 * pr][e] = (float)hx[e];
-                            xr[gg][2 * pr + 1][e] = (float)hy[e];
-                        }
-                    }
-                }
 #pragma unroll
                 for (int f = 0; f < 4; ++f) {
                     f32x4 u = acc[f][gg] + bvv[gg];
                     if constexpr (SCALED) u *= scv[gg];
                     const f32x4 v = xr[gg][f] + u;
                     acc[f][gg] = v;
-                    if constexpr (!X16)
-                        if (interior || mrow[f] < p.M) *reinterpret_cast<f32x4*>(xo + ro[f] + gg * 16) = v;
+                    if (interior || mrow[f] < p.M) *reinterpret_cast<f32x4*>(xo + ro[f] + gg * 16) = v;
                     if constexpr (RLN) sum[f][gg >> 2] += (v[0] + v[1]) + (v[2] + v[3]);
                 }
             };
@@ -464,7 +432,11 @@ static hipError_t launch_duo_t(const GemmArgs& a, hipStream_t s) {
     const int tiles_m = (a.M + 127) / 128, tiles_n = a.N / 256;
     const int n_tiles = tiles_m * tiles_n;
     const size_t a_bytes = (size_t)tiles_m * 128 * a.lda * 2;
+#ifdef HG_EXPERIMENTS
     static const int gsz_env = []() { const char* e = getenv("HG_RING_GSZ"); return e ? atoi(e) : 0; }();
+#else
+    constexpr int gsz_env = 0;
+#endif
     int gsz = gsz_env > 0 ? gsz_env : (int)((1536 * 1024) / ((size_t)512 * a.K));
     if (gsz < 3) gsz = 3;
     if (gsz > tiles_n) gsz = tiles_n;
@@ -519,7 +491,6 @@ bool gemm_duo_ok(int epi, const GemmArgs& a) {
     if (Mp * a.lda * 2 >= (1ull << 31) || (size_t)a.N * a.K * 2 >= (1ull << 31)) return false;
     if (epi == EPI_RESID_LN_F32 || epi == EPI_SCALE_RESID_LN_F32)
         return a.out2 && a.stats && a.mu && a.stats_ld == 4 * (a.N / 256) && (epi == EPI_RESID_LN_F32 || a.pos);
-    if (epi == EPI_X16_SCALE_LN) return a.out2 && a.stats && a.pos && a.stats_ld == 4 * (a.N / 256);
     return epi == EPI_BIAS_F16 || epi == EPI_BIAS_QGELU_F16 || epi == EPI_BIAS_RELU_F16 || epi == EPI_BIAS_RESID_F32 ||
            epi == EPI_BIAS_F32 || epi == EPI_BIAS_RELU_F32 || epi == EPI_PATCH_F32;
 }
@@ -535,7 +506,6 @@ hipError_t launch_gemm_duo(int epi, const GemmArgs& a, hipStream_t s) {
         case EPI_PATCH_F32: return launch_duo_t<EPI_PATCH_F32>(a, s);
         case EPI_RESID_LN_F32: return launch_duo_t<EPI_RESID_LN_F32>(a, s);
         case EPI_SCALE_RESID_LN_F32: return launch_duo_t<EPI_SCALE_RESID_LN_F32>(a, s);
-        case EPI_X16_SCALE_LN: return launch_duo_t<EPI_X16_SCALE_LN>(a, s);
         default: return hipErrorInvalidValue;
     }
 }

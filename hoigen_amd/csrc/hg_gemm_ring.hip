@@ -83,20 +83,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     constexpr int N1 = 2 * GA + 3 * GB, N2 = 3 * GA + 2 * GB;
     constexpr bool RLN = (EPI == EPI_RESID_LN_F32);    // residual + centred fp16 copy + LayerNorm statistics (MF = 4)
     constexpr bool RESID = (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_SCALE_RESID_F32 || RLN);
-    // Stream-K (256x256 residual kernels, GemmArgs::sk_ws): the K-tiles of an XCD's tile list are dealt out evenly to its
-    // workgroups as ONE contiguous range each, so a workgroup's first item may be the tail of a tile (k >= kb: its accumulators
-    // go to the workspace, "dump") and its last item the head of one (k < ke: it adds the partner's dump and runs the epilogue,
-    // "join").  N = 768 at batch 256: 591 tiles = 2.31 rounds of work instead of 3 rounds of time.
-    constexpr bool SKC = (MF == 4 && RESID && !PH2);      // (the residual epilogues run the four-phase loop)
-    typedef unsigned u32x4_sk __attribute__((ext_vector_type(4)));
-    constexpr int SK_AUX = 1 | 16;      // sc0 sc1: the stream-K workspace bypasses the (per-XCD, mutually incoherent) L2s
     // epilogue store instructions per wave (vmcnt immediates are 6 bits: anything above is clamped, i.e. stricter)
     // (fp16 outputs leave as paired 16-byte stores: half as many; counting too many here would let the first waits of
     // the next tile pass before its operands have landed)
     constexpr bool F16_STORES = (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_BIAS_RELU_F16 ||
                                  EPI == EPI_LN_BIAS_F16 || EPI == EPI_LN_BIAS_QGELU_F16);
-    constexpr bool VRP = (EPI == EPI_VAE_REPARAM_F32);     // mean | log_var tile halves -> mean, log_var, z, z16
-    constexpr int E_RAW = RLN ? 8 * MF + 4 * MF + 2 * MF : (VRP ? 14 * MF : (F16_STORES ? 4 * MF : 8 * MF));
+    constexpr int E_RAW = RLN ? 8 * MF + 4 * MF + 2 * MF : (F16_STORES ? 4 * MF : 8 * MF);
     constexpr int E = E_RAW > 52 ? 52 : E_RAW;
     // RESID at MF = 2: the residual rows are fetched one K-tile before the epilogue (64 spare VGPRs)
     constexpr bool XPRE = RESID && MF == 2;
@@ -155,47 +147,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             tn = ngf * gsz + (rr - tm * grem);
         }
     };        // tiles slot, slot+G, ...
-    // ---- stream-K work list.  Workgroups form "lanes" of tiles_n (one per column tile, neighbours on one XCD where the count
-    // allows): a lane walks a contiguous range of row panels, its members in step on the same panel - the A panel is fetched
-    // once and shared through L2 as in the whole-tile order (dealing K-tiles along the tile LIST instead makes every workgroup
-    // stream its panels alone, three times: c_proj 289 -> 424 us).  The panels' K-tiles are dealt evenly to the lanes.
-    const bool sk = SKC ? (p.sk_ws != nullptr) : false;
-    int sk_i0 = 0, sk_k0 = 0, sk_k1 = 0, sk_S = 0, sk_col = 0, sk_partner = 0, n_items = my_tiles;
-    if constexpr (SKC) {
-        if (sk) {
-            const int w = (bid & 7) * cpx + (bid >> 3);      // XCD-major linear index
-            const int lanes = G / tiles_n;
-            if (w >= lanes * tiles_n) return;                // spare workgroups (256 = 85 lanes of 3 + 1)
-            const int lane_id = w / tiles_n;
-            sk_col = w - lane_id * tiles_n;
-            const int w2 = w + tiles_n;                      // same column tile, next lane: dumps the tail this one joins
-            sk_partner = (w2 % cpx) * 8 + w2 / cpx;
-            const long long tot = (long long)tiles_m_all * nk;
-            auto cut = [&](int j) -> long long {      // snapped to 4 K-tiles inside a tile: every part has >= 4
-                if (j >= lanes) return tot;
-                const long long c = tot * j / lanes, rr = c % nk;
-                return c - rr + ((rr + 2) & ~3LL);
-            };
-            const long long lo = cut(lane_id), hi = cut(lane_id + 1);
-            sk_i0 = (int)(lo / nk);
-            sk_k0 = (int)(lo % nk);
-            sk_k1 = (int)(hi % nk);
-            n_items = (int)(hi / nk) - sk_i0 + (sk_k1 ? 1 : 0);
-            sk_S = (int)(hi - lo);
-        }
-    }
-    // item e of this workgroup: its tile and K-tile range [kb, ke)
+    const int n_items = my_tiles;
+    // item e of this workgroup: its tile (every item sweeps all of K)
     auto item_get = [&](int e, int& tm, int& tn, int& kb, int& ke) {
         kb = 0;
         ke = nk;
-        if (sk) {
-            tm = sk_i0 + e;
-            tn = sk_col;
-            if (e == 0) kb = sk_k0;
-            if (e == n_items - 1 && sk_k1) ke = sk_k1;
-        } else {
-            tile_of(slot + e * cpx, tm, tn);
-        }
+        tile_of(slot + e * cpx, tm, tn);
     };
     if (n_items <= 0) return;
     // De-synchronised epilogues: all tiles take the same time, so every CU would store (and, for the residual
@@ -205,14 +162,14 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     {
         const int dunit = mode >> 8;                               // estimated cycles per K-tile, 0 = off
         const int max_tiles = (T8 + cpx - 1) / cpx;
-        if (dunit > 0 && my_tiles < max_tiles && !sk) {
+        if (dunit > 0 && my_tiles < max_tiles) {
             const unsigned h = ((unsigned)bid * 2654435761u) >> 24;   // 0..255
             const long long d = ((long long)(max_tiles - my_tiles) * nk * dunit * h) >> 8;
             const unsigned long long t0 = __builtin_amdgcn_s_memtime();
             while ((long long)(__builtin_amdgcn_s_memtime() - t0) < d) __builtin_amdgcn_s_sleep(32);
         }
     }
-    const int S = sk ? sk_S : my_tiles * nk;                   // K-tiles in this workgroup's stream
+    const int S = my_tiles * nk;                   // K-tiles in this workgroup's stream
 
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW =
@@ -426,45 +383,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
     for (int r = 0; r < n_items; ++r) {
         int tm, tn, kb_r, ke_r;
         item_get(r, tm, tn, kb_r, ke_r);
-        const int klen = ke_r - kb_r;
-        const bool dump = SKC ? (sk && kb_r > 0) : false;      // tail of a tile: accumulators -> workspace, no epilogue
-        const bool join = SKC ? (sk && ke_r < nk) : false;     // head of a tile: + the partner's dump, then the epilogue
-        (void)join;
+        const int klen = nk;
         const int m0 = tm * BM, n0 = tn * 256;
-        const bool post_ok = prev_full && !join;
+        const bool post_ok = prev_full;
         prev_full = m0 + BM <= p.M;
         zero_acc();
-        if constexpr (SKC) {
-            // join: the accumulators START from the partner's dump of this tile's tail (the next workgroup of this XCD's list
-            // wrote it as its FIRST item - long done) and the head's K-tiles are added on top; the loads go straight into the
-            // accumulator registers.  vmcnt is drained once: the counted waits of the K loop know nothing of these loads.
-            if (join) {
-                int* fl = p.sk_flags + sk_partner * 8 + wave;
-                // (bounded: a partner that never shows up - a launch on a second stream sharing this workspace - must not hang the
-                // GPU; the tile then comes out as NaN instead)
-                int spins = 0;
-                while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1 && spins < (1 << 22)) {
-                    __builtin_amdgcn_s_sleep(8);
-                    ++spins;
-                }
-                const bool lost = spins >= (1 << 22);
-                const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)p.sk_ws, 0, 0x7FFFFFFF, 0x00020000);
-                const int kbase = (sk_partner * 8 + wave) * (32 * 1024);
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
-#pragma unroll
-                        for (int f = 0; f < MF; ++f)
-#pragma unroll
-                            for (int g2 = 0; g2 < 2; ++g2)
-                                acc[a][b][f][g2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                    rsK, lane * 16, kbase + (((a * 2 + b) * MF + f) * 2 + g2) * 1024, SK_AUX));
-                wait_vm<0>();
-                if (lost) acc[0][0][0][0] = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
-                if (lane == 0) __hip_atomic_store(fl, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
-            }
-        }
         f32x4 xres[XPRE ? 2 : 1][XPRE ? 2 : 1][XPRE ? MF : 1][XPRE ? 2 : 1];
         // rolling residual window (ROLL): chunk c = ((ha * MF + f) * 2 + hb) * 2 + g2 is this lane's f32x4 of row
         // m0 + ha*BM/2 + wm*MF*16 + f*16 + (lane&15), columns n0 + hb*128 + wn*32 + g2*16 + 4*(lane>>4)
@@ -504,7 +427,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             }
             if (KIND < 3 || more) issue_A(1, 0, GA);      // A1 of position g+1 exists unless the stream ends here
             if constexpr (ROLL && KIND == 3) {
-                if (!dump) {      // first ROLL_W residual chunks (+ the first row group's centre) of this tile
+                {      // first ROLL_W residual chunks (+ the first row group's centre) of this tile
 #pragma unroll
                     for (int c = 0; c < ROLL_W; ++c) xw[c] = chunk_load(c);
                     if constexpr (RLN) muw[0] = p.mu[chunk_row(0)];
@@ -533,7 +456,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             if constexpr (KIND == 0) wait_vm<NP>();
             else if constexpr (KIND == 1) { if (post) wait_vm<NP + E>(); else wait_vm<NP>(); }
             else if constexpr (KIND == 2) { if (more) wait_vm<NP>(); else wait_vm<0>(); }
-            else { if (more) { if (dump) wait_vm<NP>(); else wait_vm<NP + R>(); } else wait_vm<0>(); }
+            else { if (more) wait_vm<NP + R>(); else wait_vm<0>(); }
             SEG_E(0);
             sync_fetch();
             mma(I0{}, I0{});
@@ -545,7 +468,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             if constexpr (KIND == 0) wait_vm<NP>();
             else if constexpr (KIND == 1) { if (post) wait_vm<NP + E>(); else wait_vm<NP>(); }
             else if constexpr (KIND == 2) { if (more) wait_vm<NP>(); else wait_vm<0>(); }
-            else { if (more) { if (dump) wait_vm<NP>(); else wait_vm<NP + R>(); } else wait_vm<0>(); }
+            else { if (more) wait_vm<NP + R>(); else wait_vm<0>(); }
             SEG_E(0);
             sync_fetch();
             mma(I1{}, I1{});
@@ -573,7 +496,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             const int buf = (g & 1) * STAGE;
             const bool more = g + 2 < S;          // a K-tile two positions ahead exists
             const bool post = post_ok;             // epilogue stores of the previous tile may still be pending
-            const bool xl = (XPRE || ROLL) && kt == klen - 1 && !dump;  // residual rows are fetched during the last K-tile
+            const bool xl = (XPRE || ROLL) && kt == klen - 1;  // residual rows are fetched during the last K-tile
             // ---------------- P1: fetch A0(t), W0(t); refill A1(t+1); then quadrant (0,0)
             read_A(0, buf);
             read_W(I0{}, buf);
@@ -652,32 +575,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             mma(I1{}, I0{});
             sync_mma();
                             }
-        }
-        if constexpr (SKC) {
-            // workspace: per (workgroup, wave) 32 chunks of 64 lanes x 16 B, in accumulator order - dump and join use the same
-            // (wave, lane) -> element map, so each wave hands over to the same wave of the partner: one flag per wave, no barrier
-            if (dump) {
-                // (buffer stores with a scalar offset per chunk: 32 per-chunk address pairs would not fit the register file)
-                const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)p.sk_ws, 0, 0x7FFFFFFF, 0x00020000);
-                const int kbase = (bid * 8 + wave) * (32 * 1024);
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
-#pragma unroll
-                        for (int f = 0; f < MF; ++f)
-#pragma unroll
-                            for (int g2 = 0; g2 < 2; ++g2)
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_sk, acc[a][b][f][g2]), rsK, lane * 16,
-                                                                       kbase + (((a * 2 + b) * MF + f) * 2 + g2) * 1024, SK_AUX);
-                // release without cache maintenance: the dump is written through (sc0 sc1) and read back the same way, so all it
-                // takes is the stores' acknowledgement - an agent-scope fence would write back / invalidate the XCD's whole L2 once
-                // per wave (measured: +80-90 us per launch).  (Drains vmcnt: the next item's operands have landed too.)
-                wait_vm<0>();
-                if (lane == 0) __hip_atomic_store(p.sk_flags + bid * 8 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                prev_full = false;      // nothing of this item is in flight any more
-                continue;
-            }
         }
         // ---------------- epilogue of tile r (the ring keeps prefetching the next tile meanwhile)
         SEG_B(7);
@@ -767,65 +664,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
             };
             if (m0 + BM <= p.M) f16_epilogue(std::true_type{});
             else f16_epilogue(std::false_type{});
-        } else if constexpr (VRP) {
-            // VAE encoder head: column block hb = 0 of the tile holds mean_j, hb = 1 log_var_j of the same j = tn*128 +
-            // wn*32 + g2*16 + 4q .. +3 (rows interleaved at load), so the reparameterisation runs on the accumulators.
-            // The fragment registers are dead here: all 4*MF eps chunks of the lane are fetched up front (one exposed HBM
-            // round trip per tile instead of one per row group).
-            const int q = lane >> 4;
-            const float* epsp = p.pos;
-            float* meanp = reinterpret_cast<float*>(p.out);
-            float* lvp = reinterpret_cast<float*>(p.out_hi);
-            const int jb = (n0 >> 1) + wn * 32 + 4 * q;
-            f32x4 ep[2 * MF][2];
-#pragma unroll
-            for (int rg = 0; rg < 2 * MF; ++rg) {
-                int m = m0 + (rg / MF) * (BM / 2) + wm * MF * 16 + (rg % MF) * 16 + (lane & 15);
-                m = m < p.M ? m : p.M - 1;
-#pragma unroll
-                for (int g2 = 0; g2 < 2; ++g2)
-                    ep[rg][g2] = *reinterpret_cast<const f32x4*>(epsp + (size_t)m * p.ldc + jb + g2 * 16);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-            for (int rp = 0; rp < MF; ++rp) {               // pairs of 16-row blocks (f, f + 1): the fp16 copy leaves as 16-byte stores
-                const int ha = (2 * rp) / MF, f0 = (2 * rp) % MF;
-#pragma unroll
-                for (int g2 = 0; g2 < 2; ++g2) {
-                    const int nl = n0 + wn * 32 + g2 * 16 + 4 * q;          // bias index of the mean column (+128: log_var)
-                    const f32x4 bm = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + nl * 4);
-                    const f32x4 bl = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + (nl + 128) * 4);
-                    half4 zh[2];
-#pragma unroll
-                    for (int df = 0; df < 2; ++df) {
-                        const int f = f0 + df, rg = ha * MF + f;
-                        const int m = m0 + ha * (BM / 2) + wm * MF * 16 + f * 16 + (lane & 15);
-                        const f32x4 mean = acc[ha][0][f][g2] + bm, lv = acc[ha][1][f][g2] + bl;
-                        f32x4 z;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            z[e] = reparam1(mean[e], lv[e], ep[rg][g2][e]);
-                            zh[df][e] = (half_t)z[e];
-                        }
-                        if (m < p.M) {
-                            const size_t o = (size_t)m * p.ldc + jb + g2 * 16;
-                            *reinterpret_cast<f32x4*>(meanp + o) = mean;
-                            *reinterpret_cast<f32x4*>(lvp + o) = lv;
-                            if (p.out3) *reinterpret_cast<f32x4*>(p.out3 + o) = z;
-                        }
-                    }
-                    // even 16-lane groups end up with 8 consecutive columns of block f0's row, odd groups of block f0 + 1's
-                    const u32x2 ux = __builtin_bit_cast(u32x2, zh[0]), uy = __builtin_bit_cast(u32x2, zh[1]);
-                    const auto s0 = __builtin_amdgcn_permlane16_swap(ux[0], uy[0], false, false);
-                    const auto s1 = __builtin_amdgcn_permlane16_swap(ux[1], uy[1], false, false);
-                    const u32x4 o16 = {s0[0], s1[0], s0[1], s1[1]};
-                    const int m16 = m0 + ha * (BM / 2) + wm * MF * 16 + f0 * 16 + (lane & 15) + ((q & 1) ? 16 : 0);
-                    if (m16 < p.M)
-                        *reinterpret_cast<u32x4*>(p.out2 + (size_t)m16 * p.ldc + (n0 >> 1) + wn * 32 + g2 * 16 + 4 * (q & ~1)) = o16;
-                }
-            }
         } else if constexpr (ROLL) {
             // residual epilogue through the rolling window: chunk c is consumed, stored, and its window slot is
             // refilled with chunk c + ROLL_W (the sched_barrier keeps the compiler from hoisting the refills)
@@ -948,18 +786,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ring(const GemmArgs p, const int 
 #endif
 }
 
-// stream-K needs >= 2 rounds of 256x256 tiles (a workgroup's range spans more than one tile) and K-tiles in fours
-// (lanes of N / 256 workgroups walk the row panels: at least two panels per lane, K-tiles in fours)
-static bool streamk_shape(const GemmArgs& a) {
-    const int nk = a.K / 64, tiles_m = (a.M + 255) / 256, tiles_n = a.N / 256;
-    return nk % 4 == 0 && nk >= 8 && tiles_n >= 1 && tiles_n <= 8 && tiles_m >= 2 * (256 / tiles_n);
-}
-
 template <int MF, int EPI, bool PH2 = false>
 static hipError_t launch_ring_t(const GemmArgs& a_in, hipStream_t s) {
     GemmArgs a = a_in;
     if (!a.ld2) a.ld2 = a.ldc;
-    constexpr bool SKC = MF == 4 && !PH2 && (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_SCALE_RESID_F32 || EPI == EPI_RESID_LN_F32);
     constexpr int BM = 64 * MF;
     constexpr int RING = 2 * (2 * MF * 4096 + 2 * 16384);
     constexpr bool LNC = (EPI == EPI_LN_BIAS_F16 || EPI == EPI_LN_BIAS_QGELU_F16);
@@ -987,23 +817,29 @@ static hipError_t launch_ring_t(const GemmArgs& a_in, hipStream_t s) {
     // Even rounds: the tiles take `rounds` passes over the CUs whatever the grid, so use only as many workgroups as fill every
     // round (a multiple of 8: the XCD-chunked tile order needs it).  c_fc at batch 256: 2364 tiles = 10 rounds on 240
     // workgroups instead of 9.23 on 256 - the same number of rounds with fewer CUs contending for L2 / HBM: 236-239 -> 230 us
-    // (round 3, one box; QKV's 1773 tiles stay on 256).  HG_RING_GRID overrides.
+    // (round 3, one box; QKV's 1773 tiles stay on 256).  (HG_RING_GRID overrides in -DHG_EXPERIMENTS builds.)
     if (MF == 4 && n_tiles > n_cu) {
         const int rounds = (n_tiles + n_cu - 1) / n_cu;
         const int g8 = (((n_tiles + rounds - 1) / rounds) + 7) & ~7;
         if (g8 < grid) grid = g8;
     }
+#ifdef HG_EXPERIMENTS
     if (const char* e = getenv("HG_RING_GRID")) { const int v = atoi(e); if (v >= 8 && v <= n_cu && v <= n_tiles) grid = v; }
-    if (SKC && a.sk_ws && a.sk_flags && streamk_shape(a) && n_cu >= 8 && tiles_m >= 2 * ((n_cu & ~7) / tiles_n)) grid = n_cu & ~7;   // every CU, equal shares
-    else a.sk_ws = nullptr;
+#endif
     const size_t a_bytes = (size_t)tiles_m * BM * a.lda * 2;      // A is allocated with rows padded to 256
+    // start stagger: estimated cycles per K-tile (a deliberate under-estimate).  The timing-experiment switches HG_RING_MODE,
+    // HG_RING_DELAY (0 = no stagger) and HG_RING_GSZ are read in -DHG_EXPERIMENTS builds only
+#ifdef HG_EXPERIMENTS
     static const int mode = []() {
         const char* e = getenv("HG_RING_MODE");
-        // start stagger: estimated cycles per K-tile (a deliberate under-estimate; HG_RING_DELAY=0 turns it off)
         const char* d = getenv("HG_RING_DELAY");
         return (e ? atoi(e) & 0xFF : 0) | ((d ? atoi(d) : (MF == 4 ? 3000 : 1800)) << 8);
     }();
     static const int gsz_env = []() { const char* e = getenv("HG_RING_GSZ"); return e ? atoi(e) : 0; }();
+#else
+    constexpr int mode = (MF == 4 ? 3000 : 1800) << 8;
+    constexpr int gsz_env = 0;
+#endif
     // column tiles per L2 group: W slices of one group (gsz * 256 rows * K * 2 B) should fit ~1.5 MiB, but
     // never fewer than 3: an A panel that is not shared by neighbouring column tiles is re-read from HBM once
     // per column tile (c_proj, K = 3072: 310 MB of activations x 3)
@@ -1084,19 +920,23 @@ bool gemm_ring_ok(const GemmArgs& a) {
     return true;
 }
 
-bool gemm_streamk_shape(int epi, const GemmArgs& a) {
-    return (epi == EPI_BIAS_RESID_F32 || epi == EPI_SCALE_RESID_F32 || epi == EPI_RESID_LN_F32) && gemm_ring_ok(a) && streamk_shape(a);
-}
-
 bool gemm_ln_ok(int epi, const GemmArgs& a) {
     if (!gemm_ring_ok(a)) return false;
-    if (epi == EPI_VAE_REPARAM_F32) return a.out && a.out_hi && a.out2 && a.pos && a.ldc * 2 == a.N;
     if (epi == EPI_RESID_LN_F32) return gemm_ring2_ok(a) && a.out2 && a.stats && a.mu && a.stats_ld == 4 * (a.N / 256);
     return a.cs && a.mr && a.N <= 3584;      // 128 KiB ring + 2 * N * 4 + 2 KiB of LDS; mr readable for padded rows
 }
 
+// 256x256 tiles: two phases per K-tile, except with the residual epilogues (their rolling window does not fit beside the
+// two-phase loop's fragment registers: those instantiations would spill and are never built)
+template <int E>
+static hipError_t launch_big(const GemmArgs& a, hipStream_t s, bool ph2) {
+    constexpr bool resid = (E == EPI_BIAS_RESID_F32 || E == EPI_SCALE_RESID_F32 || E == EPI_RESID_LN_F32);
+    if constexpr (resid) return launch_ring_t<4, E, false>(a, s);
+    else return ph2 ? launch_ring_t<4, E, true>(a, s) : launch_ring_t<4, E, false>(a, s);
+}
+
 hipError_t launch_gemm_ring(int epi, const GemmArgs& a, hipStream_t s) {
-    const bool lnc = (epi == EPI_LN_BIAS_F16 || epi == EPI_LN_BIAS_QGELU_F16 || epi == EPI_VAE_REPARAM_F32);   // this kernel only
+    const bool lnc = (epi == EPI_LN_BIAS_F16 || epi == EPI_LN_BIAS_QGELU_F16);   // this kernel only
     const bool resid = (epi == EPI_BIAS_RESID_F32 || epi == EPI_SCALE_RESID_F32 || epi == EPI_RESID_LN_F32);
     // 256x256 tiles when they fill the chip evenly enough, else 128x256 (N = 768 GEMMs: 591 vs 1182 tiles).
     // The 128x256 kernel needs 50 % more global->LDS traffic per FLOP and runs at ~0.8 of a 256x256 tile's time
@@ -1104,7 +944,13 @@ hipError_t launch_gemm_ring(int epi, const GemmArgs& a, hipStream_t s) {
     // as rounds(256) <= 0.8 * rounds(128): N = 768, M = 50432: 3 vs 5 * 0.8.
     const int t256 = ((a.M + 255) / 256) * (a.N / 256), t128 = ((a.M + 127) / 128) * (a.N / 256);
     const int rounds = (t256 + 255) / 256, rounds128 = (t128 + 255) / 256;
+#ifdef HG_EXPERIMENTS
     static const int force_big = []() { const char* e = getenv("HG_RING_BIG"); return e ? atoi(e) : 0; }();
+    static const bool ph2 = []() { const char* e = getenv("HG_RING_PH2"); return e ? atoi(e) != 0 : true; }();
+#else
+    constexpr int force_big = 0;
+    constexpr bool ph2 = true;
+#endif
     bool big = t256 >= 256 && (double)t256 / (rounds * 256.0) >= 0.9;
     // ... or when its whole passes (even rounds: launch_ring_t uses only as many workgroups as fill them) still beat the
     // 128-row kernel's: text-tower QKV, M = 46 200, N = 1536: 5 passes of 256x256 against 8.5 of 128x256 at ~0.8 of the time
@@ -1114,19 +960,16 @@ hipError_t launch_gemm_ring(int epi, const GemmArgs& a, hipStream_t s) {
     // (fp16 copy + statistics: 387 MB per launch) the epilogue is an HBM burst of every CU at once, and three big
     // bursts overlap worse than five small ones (K = 768: 154 vs 127 us; K = 3072: 300 vs 303): keep 128 rows.
     if (resid && epi != EPI_RESID_LN_F32 && t256 >= 256 && (double)rounds <= 0.8 * rounds128 + 1e-9) big = true;
-    const bool sk = resid && a.sk_ws && a.sk_flags && streamk_shape(a);      // stream-K exists in the 256x256 kernel only
-    if (sk) big = true;
     if (force_big == 1) big = true;
     if (force_big == 2 || force_big == 3) big = false;
     if (epi == EPI_RESID_LN_F32 && !big) return launch_gemm_ring2(epi, a, s);     // no 128-row variant in this kernel
     if (!big && force_big != 3 && !lnc && gemm_ring2_ok(a)) return launch_gemm_ring2(epi, a, s);   // 128x256, two-phase
-    // 256x256 tiles run two phases per K-tile (32 MFMAs per segment): -4..8 % vs four phases; HG_RING_PH2=0 = four
-    static const bool ph2 = []() { const char* e = getenv("HG_RING_PH2"); return e ? atoi(e) != 0 : true; }();
+    // 256x256 tiles run two phases per K-tile (32 MFMAs per segment): -4..8 % vs four phases (HG_RING_PH2=0 in experiments builds)
     // ... except with the residual epilogues: their rolling window does not fit beside the two-phase loop's fragment
     // registers (9-21 spilled VGPRs, 4-10 % slower than four phases)
 #define HG_RING(E)                                                         \
     case E:                                                                \
-        return big ? (ph2 && !resid ? launch_ring_t<4, E, true>(a, s) : launch_ring_t<4, E, false>(a, s)) : launch_ring_t<2, E, false>(a, s)
+        return big ? launch_big<E>(a, s, ph2) : launch_ring_t<2, E, false>(a, s)
     switch (epi) {
         HG_RING(EPI_BIAS_F16);
         HG_RING(EPI_BIAS_QGELU_F16);
@@ -1138,7 +981,6 @@ hipError_t launch_gemm_ring(int epi, const GemmArgs& a, hipStream_t s) {
         HG_RING(EPI_SCALE_RESID_F32);
         HG_RING(EPI_LN_BIAS_F16);
         HG_RING(EPI_LN_BIAS_QGELU_F16);
-        HG_RING(EPI_VAE_REPARAM_F32);
         case EPI_RESID_LN_F32: return launch_ring_t<4, EPI_RESID_LN_F32, false>(a, s);
         default: return hipErrorInvalidValue;
     }

@@ -535,13 +535,19 @@ static hipError_t launch_ring2_t(const GemmArgs& a, hipStream_t s) {
     const int n_tiles = tiles_m * tiles_n;
     const int grid = n_tiles < n_cu ? n_tiles : n_cu;
     const size_t a_bytes = (size_t)tiles_m * 128 * a.lda * 2;
+    // start stagger: estimated cycles per K-tile (a deliberate under-estimate); HG_RING_MODE / HG_RING_DELAY / HG_RING_GSZ are
+    // read in -DHG_EXPERIMENTS builds only
+#ifdef HG_EXPERIMENTS
     static const int mode = []() {
         const char* e = getenv("HG_RING_MODE");
-        // start stagger: estimated cycles per K-tile (a deliberate under-estimate; HG_RING_DELAY=0 turns it off)
         const char* d = getenv("HG_RING_DELAY");
         return (e ? atoi(e) & 0xFF : 0) | ((d ? atoi(d) : 2200) << 8);
     }();
     static const int gsz_env = []() { const char* e = getenv("HG_RING_GSZ"); return e ? atoi(e) : 0; }();
+#else
+    constexpr int mode = 2200 << 8;
+    constexpr int gsz_env = 0;
+#endif
     // column tiles per L2 group: W slices of one group (gsz * 256 rows * K * 2 B) should fit ~1.5 MiB, but
     // never fewer than 3: an A panel that is not shared by neighbouring column tiles is re-read from HBM once
     // per column tile (c_proj, K = 3072: 310 MB of activations x 3)

@@ -30,16 +30,7 @@ enum Epilogue : int {
     EPI_MU_BIAS_RELU_F32 = 11,
     // EPI_RESID_LN_F32 with the update scaled per column: out fp32 += (acc + bias) * pos[n]; fp16 copy + statistics
     // (adapter up_proj: LayerNorm folding stays on behind the adapter; duo kernel only)
-    EPI_SCALE_RESID_LN_F32 = 12,
-    // CoOp-VAE encoder head (main_coop_vae.py:276-279,445-447): W = the mean / log_var weights stacked with their rows
-    // interleaved in blocks of 128 (tile column block 0 = mean columns j, block 1 = log_var columns j), so one lane holds
-    // mean_j and log_var_j of a row:  mean = out[m][j], log_var = out_hi[m][j], z = exp(0.5 log_var) * eps + mean with
-    // eps = pos[m][j] -> out3 (fp32, nullable) and out2 (fp16, the generator's operand); ring kernels only
-    EPI_VAE_REPARAM_F32 = 13,
-    // adapter up_proj without touching the fp32 stream (variant C, K-concatenated out-proj): the centred fp16 copy out2 is
-    // updated IN PLACE, out2 = fp16(out2 + (acc + bias) * pos[n]), and the statistics of the updated (centred) values are
-    // emitted; the stream itself receives the same update inside the out-proj GEMM ([att | d] x [W_out | scale W_up]); duo only
-    EPI_X16_SCALE_LN = 14
+    EPI_SCALE_RESID_LN_F32 = 12
 };
 
 struct GemmArgs {
@@ -62,16 +53,8 @@ struct GemmArgs {
     // (the stacked mean | log_var GEMM of the VAE encoder writes its two halves straight into the caller's tensors)
     void* out_hi = nullptr;
     int n_split = 0;                     // multiple of 16
-    float* out3 = nullptr;               // EPI_VAE_REPARAM_F32: z (fp32), leading dimension ldc; may be null
     unsigned long long* dbg = nullptr;   // diagnostics: s_memtime totals (HG_STAMPS build), normally null
-    // stream-K of the 256x256 residual kernels (hg_gemm_ring.hip): workspace of GEMM_SK_WS_BYTES per workgroup and 8 flags
-    // (zero between launches) per workgroup; null = whole tiles only.  One launch at a time per workspace.
-    float* sk_ws = nullptr;
-    int* sk_flags = nullptr;
 };
-constexpr size_t GEMM_SK_WS_BYTES = 256 * 1024, GEMM_SK_FLAG_BYTES = 8 * sizeof(int);
-// would launch_gemm run this residual GEMM as stream-K if given a workspace? (shape test only)
-bool gemm_streamk_shape(int epi, const GemmArgs& a);
 
 // Requirements: N % 128 == 0, K % 64 == 0, A readable for rows < M, 16-byte aligned rows.
 // A must be allocated with its row count padded to a multiple of 256 (the ring kernel's DMA reads whole
@@ -123,6 +106,8 @@ hipError_t launch_gather_rows(const int32_t* ids, const float* table, float* out
 hipError_t launch_eot_argmax(const int32_t* ids, int T, int L, int32_t* eot, int32_t* max_eot, hipStream_t s);
 // out[i] = min(max(in[i], 0), Leff - 1); *flag = 1 (host-mapped, sticky) if any in[i] >= Leff.  in may equal out.
 hipError_t launch_clamp_eot(const int32_t* in, int n, int Leff, int32_t* out, int32_t* flag, hipStream_t s);
+// out[0..n) = NaN if *flag != 0 (flag: device-visible, set earlier on the same stream)
+hipError_t launch_poison_if_flag(float* out, size_t n, const int32_t* flag, hipStream_t s);
 hipError_t launch_f32_to_f16(const float* in, half_t* out, size_t n, hipStream_t s);
 hipError_t launch_f16_to_f32(const half_t* in, float* out, size_t n, hipStream_t s);
 // out[c][r] = in[r][c]  (fp32 or fp16 in -> fp16 out), used for `proj` / `text_projection` [in,out]
@@ -162,11 +147,6 @@ hipError_t launch_layernorm_rowstats(float* x, const float* w, const float* b, h
 // centred: the statistics are those of ALREADY CENTRED values (EPI_X16_SCALE_LN): mr = (mean, rstd), mu stays
 hipError_t launch_finalize_stats(const float* stats, float* mr, float* mu, int M, int nt, int gw, hipStream_t s,
                                  float* muc = nullptr, bool centred = false);
-// K-concatenated out-proj operand of a block with an adapter: wk [N, K + d] = [w_out | fp16(scale[n] * up_w[n][:])],
-// bk [N] = b_out + scale * up_b
-hipError_t launch_concat_upproj(const half_t* w_out, const float* b_out, const half_t* up_w, const float* up_b,
-                                const float* scale, half_t* wk, float* bk, int N, int K, int d, hipStream_t s);
-
 #define HG_PRE_HDR 24   // header words per box in the pre-processing table (layout: hg_preproc.hip)
 // ---- crop pre-processing (hg_preproc.hip): head = per-box headers written by the host, tab receives the weight
 // tables at word offsets tab_off[box]; tmp = uint8 scratch for the horizontal pass; out fp32 [n,3,n_px,n_px]; out_u8 (nullable) uint8

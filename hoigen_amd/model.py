@@ -82,6 +82,7 @@ class _Ctx:
     def __init__(self):
         self.handle = None
         self.device_index = None
+        self.options = {}            # hg_set_option values, re-applied whenever the native context is (re)created
 
     def get(self, device: torch.device) -> int:
         idx = device.index if device.index is not None else torch.cuda.current_device()
@@ -91,7 +92,16 @@ class _Ctx:
             if not h:
                 raise RuntimeError(f"hoigen_amd: hg_create({idx}) failed - no HIP device; there is no CPU fallback")
             self.handle, self.device_index = h, idx
+            for k, v in self.options.items():
+                self.check(_lib.lib().hg_set_option(h, k.encode(), int(v)), f"hg_set_option({k})")
         return self.handle
+
+    def set_option(self, key: str, value: int) -> None:
+        """Behaviour option of this model's native context (include/hoigen_amd.h: hg_set_option), e.g. ``last_block_row0``,
+        ``ln_fuse``, ``adapter_fuse``, ``adapter_fold``, ``chunk_rows``.  Survives a move to another device."""
+        if self.handle is not None:
+            self.check(_lib.lib().hg_set_option(self.handle, key.encode(), int(value)), f"hg_set_option({key})")
+        self.options[key] = int(value)
 
     def check(self, rc: int, what: str) -> None:
         if rc != 0:
@@ -109,14 +119,17 @@ class _Ctx:
     def __del__(self):
         self.close()
 
-    def __deepcopy__(self, memo):      # a copied module gets its own native context
-        return _Ctx()
+    def __deepcopy__(self, memo):      # a copied module gets its own native context (with the same options)
+        c = _Ctx()
+        c.options = dict(self.options)
+        return c
 
     def __getstate__(self):            # never pickle a native handle
-        return {}
+        return {"options": dict(self.options)}
 
     def __setstate__(self, state):
         self.handle, self.device_index = None, None
+        self.options = dict(state.get("options", {})) if isinstance(state, dict) else {}
 
 
 def _sig(params) -> tuple:
@@ -378,6 +391,10 @@ class VisionTransformer(nn.Module):
                         "hg_encode_image")
         return out
 
+    def set_option(self, key: str, value: int) -> None:
+        """Behaviour option of this tower's native context (include/hoigen_amd.h: hg_set_option)."""
+        self._ctx.set_option(key, value)
+
     @torch.no_grad()
     def forward_trace(self, x: torch.Tensor):
         """Test hook: (embedding [B,E], CLS rows after ln_pre and every block [layers+1,B,D])."""
@@ -510,6 +527,11 @@ class CLIP(nn.Module):
         self._trunc_memo = (weakref.ref(tokens), ver_now, tokens.data_ptr(), n) if ver_now is not None else (None, 0, 0, 0)
         return n
 
+    def set_option(self, key: str, value: int) -> None:
+        """Behaviour option (hg_set_option) for both towers of this model."""
+        self.visual.set_option(key, value)
+        self._ctx.set_option(key, value)
+
     # -- public API -----------------------------------------------------------------------------------
     def encode_image(self, image: torch.Tensor):
         """clipnet/model.py:336-337 / CLIP_models_adapter_prior2.py:875-876."""
@@ -530,8 +552,10 @@ class CLIP(nn.Module):
             trunc = self._trunc_len(text)
         ids = text.detach().to(device=dev, dtype=torch.int32).contiguous()
         out = torch.empty(T, self.text_projection.shape[1], device=dev, dtype=torch.float32)
-        self._ctx.check(_lib.lib().hg_encode_text_ids(h, ids.data_ptr(), T, L, out.data_ptr(), trunc,
-                                                      _stream_ptr(dev)), "hg_encode_text_ids")
+        rc = _lib.lib().hg_encode_text_ids(h, ids.data_ptr(), T, L, out.data_ptr(), trunc, _stream_ptr(dev))
+        if rc:
+            self._trunc_memo = (None, 0, 0, 0)      # a stale truncation length must not survive the error it caused
+        self._ctx.check(rc, "hg_encode_text_ids")
         return out.to(self.dtype)
 
     @_inference_only
@@ -549,8 +573,10 @@ class CLIP(nn.Module):
         eot32 = eot.to(device=dev, dtype=torch.int32).contiguous()
         pf = prompts.detach().to(torch.float32).contiguous()
         out = torch.empty(R, self.text_projection.shape[1], device=dev, dtype=torch.float32)
-        self._ctx.check(_lib.lib().hg_encode_text_embeds(h, pf.data_ptr(), eot32.data_ptr(), R, L, out.data_ptr(), trunc,
-                                                         _stream_ptr(dev)), "hg_encode_text_embeds")
+        rc = _lib.lib().hg_encode_text_embeds(h, pf.data_ptr(), eot32.data_ptr(), R, L, out.data_ptr(), trunc, _stream_ptr(dev))
+        if rc:
+            self._trunc_memo = (None, 0, 0, 0)
+        self._ctx.check(rc, "hg_encode_text_embeds")
         return out
 
     def forward(self, image, text):

@@ -31,10 +31,12 @@ def weights_init(m):
 class _Slot:
     """One weight slot (``kind``: "vae" or "mlp") of the per-device context that every VAE-family module on that device shares:
     one workspace however many Encoder / Generator / VAE / mlp_net objects exist (the three-branch sampler of
-    main_tip_finetune.py:759-824 holds nine).  The slot goes back to the pool when its module dies.  As with any native context:
-    one launch at a time per device, i.e. callers that use several streams serialise these modules themselves."""
-    _lock = threading.Lock()
-    _pools = {}          # device index -> {"ctx": _Ctx, "vae": [free slots], "mlp": [free slots]}
+    main_tip_finetune.py:759-824 holds nine).  The slot goes back to the pool when its module dies.  The shared context serves
+    one call at a time: ``session`` holds the pool's lock for the duration of a module's load + forward (threads) and, when the
+    calling stream differs from the one the context was last used on, makes it wait for that use (streams) - modules driven from
+    different streams or threads stay correct, they just do not overlap.  At most ``HG_MAX_SLOTS`` live modules of a kind per device."""
+    _lock = threading.RLock()      # re-entrant: a GC pass inside get() may finalise another module's slot on this thread
+    _pools = {}          # device index -> {"ctx": _Ctx, "vae": [free slots], "mlp": [free slots], "stream": id, "event": Event}
 
     def __init__(self, kind: str):
         self.kind, self.idx, self.slot = kind, None, None
@@ -57,6 +59,10 @@ class _Slot:
             ctx = _Slot._pools[idx]["ctx"]
         return ctx, ctx.get(device), self.slot, fresh
 
+    def session(self, device: torch.device):
+        """Context manager around one module call: (context, handle, slot, fresh) with the shared context reserved."""
+        return _Session(self, device)
+
     def _give(self):
         if self.idx is not None and self.idx in _Slot._pools:
             _Slot._pools[self.idx][self.kind].append(self.slot)
@@ -77,6 +83,37 @@ class _Slot:
 
     def __setstate__(self, state):
         self.kind, self.idx, self.slot = state["kind"], None, None
+
+
+class _Session:
+    def __init__(self, slot: _Slot, device: torch.device):
+        self.slot, self.device = slot, device
+
+    def __enter__(self):
+        _Slot._lock.acquire()
+        try:
+            got = self.slot.get(self.device)
+            pool = _Slot._pools[self.slot.idx]
+            cur = torch.cuda.current_stream(self.device)
+            ev = pool.get("event")
+            if ev is not None and pool.get("stream") != cur.cuda_stream:
+                cur.wait_event(ev)              # the workspace's previous user ran on another stream
+            self.pool, self.cur = pool, cur
+            return got
+        except BaseException:
+            _Slot._lock.release()
+            raise
+
+    def __exit__(self, *exc):
+        try:
+            ev = self.pool.get("event")
+            if ev is None:
+                ev = self.pool["event"] = torch.cuda.Event()
+            ev.record(self.cur)
+            self.pool["stream"] = self.cur.cuda_stream
+        finally:
+            _Slot._lock.release()
+        return False
 
 
 class _Seq(nn.Module):
@@ -120,23 +157,23 @@ class Encoder(nn.Module):
     @torch.no_grad()
     def forward(self, x: torch.Tensor):
         _require_cuda(x, "Encoder input")
-        ctx, h, slot, fresh = self._slot.get(x.device)
-        if fresh:
-            self._sig = None
-        sig = _sig(self.parameters())
-        if sig != self._sig:
-            w = _lib.hg_vae_weights()
-            self._weights(w)
-            ctx.check(_lib.lib().hg_load_vae(h, slot, C.byref(w)), "hg_load_vae")
-            self._sig = sig
-        xf = _f32(x)
-        R = xf.shape[0]
-        mean, logvar = torch.empty_like(xf), torch.empty_like(xf)
-        zeros = torch.zeros_like(xf)          # eps = 0: z is not requested
-        ctx.check(_lib.lib().hg_vae_forward(h, slot, xf.data_ptr(), zeros.data_ptr(), R, mean.data_ptr(),
-                                                  logvar.data_ptr(), None, None, _stream_ptr(x.device)),
-                        "hg_vae_forward")
-        return mean, logvar
+        with self._slot.session(x.device) as (ctx, h, slot, fresh):
+            if fresh:
+                self._sig = None
+            sig = _sig(self.parameters())
+            if sig != self._sig:
+                w = _lib.hg_vae_weights()
+                self._weights(w)
+                ctx.check(_lib.lib().hg_load_vae(h, slot, C.byref(w)), "hg_load_vae")
+                self._sig = sig
+            xf = _f32(x)
+            R = xf.shape[0]
+            mean, logvar = torch.empty_like(xf), torch.empty_like(xf)
+            zeros = torch.zeros_like(xf)          # eps = 0: z is not requested
+            ctx.check(_lib.lib().hg_vae_forward(h, slot, xf.data_ptr(), zeros.data_ptr(), R, mean.data_ptr(),
+                                                      logvar.data_ptr(), None, None, _stream_ptr(x.device)),
+                            "hg_vae_forward")
+            return mean, logvar
 
 
 class Generator(nn.Module):
@@ -160,20 +197,20 @@ class Generator(nn.Module):
     @torch.no_grad()
     def forward(self, z: torch.Tensor) -> torch.Tensor:
         _require_cuda(z, "Generator input")
-        ctx, h, slot, fresh = self._slot.get(z.device)
-        if fresh:
-            self._sig = None
-        sig = _sig(self.parameters())
-        if sig != self._sig:
-            w = _lib.hg_vae_weights()
-            self._weights(w)
-            ctx.check(_lib.lib().hg_load_vae(h, slot, C.byref(w)), "hg_load_vae")
-            self._sig = sig
-        zf = _f32(z)
-        out = torch.empty_like(zf)
-        ctx.check(_lib.lib().hg_generator(h, slot, zf.data_ptr(), zf.shape[0], out.data_ptr(),
-                                                _stream_ptr(z.device)), "hg_generator")
-        return out
+        with self._slot.session(z.device) as (ctx, h, slot, fresh):
+            if fresh:
+                self._sig = None
+            sig = _sig(self.parameters())
+            if sig != self._sig:
+                w = _lib.hg_vae_weights()
+                self._weights(w)
+                ctx.check(_lib.lib().hg_load_vae(h, slot, C.byref(w)), "hg_load_vae")
+                self._sig = sig
+            zf = _f32(z)
+            out = torch.empty_like(zf)
+            ctx.check(_lib.lib().hg_generator(h, slot, zf.data_ptr(), zf.shape[0], out.data_ptr(),
+                                                    _stream_ptr(z.device)), "hg_generator")
+            return out
 
 
 class VAE:
@@ -193,23 +230,23 @@ class VAE:
     @torch.no_grad()
     def __call__(self, x: torch.Tensor, eps: Optional[torch.Tensor] = None):
         _require_cuda(x, "VAE input")
-        ctx, h, slot, fresh = self._slot.get(x.device)
-        if fresh:
-            self._sig = None
-        sig = _sig(list(self.netE.parameters()) + list(self.netG.parameters()))
-        if sig != self._sig:
-            w = _lib.hg_vae_weights()
-            self.netE._weights(w)
-            self.netG._weights(w)
-            ctx.check(_lib.lib().hg_load_vae(h, slot, C.byref(w)), "hg_load_vae")
-            self._sig = sig
-        xf = _f32(x)
-        ef = torch.randn_like(xf) if eps is None else _f32(eps)
-        mean, logvar, z, bias = (torch.empty_like(xf) for _ in range(4))
-        ctx.check(_lib.lib().hg_vae_forward(h, slot, xf.data_ptr(), ef.data_ptr(), xf.shape[0], mean.data_ptr(),
-                                                  logvar.data_ptr(), z.data_ptr(), bias.data_ptr(),
-                                                  _stream_ptr(x.device)), "hg_vae_forward")
-        return mean, logvar, z, bias
+        with self._slot.session(x.device) as (ctx, h, slot, fresh):
+            if fresh:
+                self._sig = None
+            sig = _sig(list(self.netE.parameters()) + list(self.netG.parameters()))
+            if sig != self._sig:
+                w = _lib.hg_vae_weights()
+                self.netE._weights(w)
+                self.netG._weights(w)
+                ctx.check(_lib.lib().hg_load_vae(h, slot, C.byref(w)), "hg_load_vae")
+                self._sig = sig
+            xf = _f32(x)
+            ef = torch.randn_like(xf) if eps is None else _f32(eps)
+            mean, logvar, z, bias = (torch.empty_like(xf) for _ in range(4))
+            ctx.check(_lib.lib().hg_vae_forward(h, slot, xf.data_ptr(), ef.data_ptr(), xf.shape[0], mean.data_ptr(),
+                                                      logvar.data_ptr(), z.data_ptr(), bias.data_ptr(),
+                                                      _stream_ptr(x.device)), "hg_vae_forward")
+            return mean, logvar, z, bias
 
 
 class mlp_net(nn.Module):
@@ -227,22 +264,22 @@ class mlp_net(nn.Module):
     @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         _require_cuda(x, "mlp_net input")
-        ctx, h, slot, fresh = self._slot.get(x.device)
-        if fresh:
-            self._sig = None
-        sig = _sig(self.parameters())
-        if sig != self._sig:
-            t = _lib.tensor
-            w = _lib.hg_mlp_weights(self.dims[0], self.dims[1], self.dims[2], t(self.net[0].weight),
-                                    t(self.net[0].bias), t(self.net[2].weight), t(self.net[2].bias),
-                                    t(self.net[4].weight), t(self.net[4].bias))
-            ctx.check(_lib.lib().hg_load_mlp(h, slot, C.byref(w)), "hg_load_mlp")
-            self._sig = sig
-        xf = _f32(x)
-        out = torch.empty(xf.shape[0], self.dims[2], device=x.device, dtype=torch.float32)
-        ctx.check(_lib.lib().hg_mlp_net(h, slot, xf.data_ptr(), xf.shape[0], out.data_ptr(), _stream_ptr(x.device)),
-                        "hg_mlp_net")
-        return out
+        with self._slot.session(x.device) as (ctx, h, slot, fresh):
+            if fresh:
+                self._sig = None
+            sig = _sig(self.parameters())
+            if sig != self._sig:
+                t = _lib.tensor
+                w = _lib.hg_mlp_weights(self.dims[0], self.dims[1], self.dims[2], t(self.net[0].weight),
+                                        t(self.net[0].bias), t(self.net[2].weight), t(self.net[2].bias),
+                                        t(self.net[4].weight), t(self.net[4].bias))
+                ctx.check(_lib.lib().hg_load_mlp(h, slot, C.byref(w)), "hg_load_mlp")
+                self._sig = sig
+            xf = _f32(x)
+            out = torch.empty(xf.shape[0], self.dims[2], device=x.device, dtype=torch.float32)
+            ctx.check(_lib.lib().hg_mlp_net(h, slot, xf.data_ptr(), xf.shape[0], out.data_ptr(), _stream_ptr(x.device)),
+                            "hg_mlp_net")
+            return out
 
 
 # ---------------------------------------------------------------------------------------------

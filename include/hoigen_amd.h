@@ -231,6 +231,18 @@ int hg_preprocess_crops(hg_ctx*, const uint8_t* img, int H, int W, const int32_t
 int hg_vae_loss(hg_ctx*, const float* recon, const float* x, const float* mean, const float* logvar,
                 int R, int D, float* loss, void* stream);
 
+/* ---- behaviour options (no reference counterpart) ------------------------------------------
+ * Per context; the environment only supplies the initial values at hg_create (variable in brackets).  Keys:
+ *   "last_block_row0" [HG_LAST_BLOCK_ROW0] 1: towers without token outputs run their LAST block on the one row per sequence
+ *                      that reaches the output (class / EOT token); 0: on every row, like the reference
+ *   "ln_fuse"         [HG_LN_FUSE]         1: LayerNorm folded into the GEMMs (vision tower, M >= 512); 0: separate kernels
+ *   "adapter_fuse"    [HG_ADAPTER_FUSE]    1: ... also around the instance adapters of variant C
+ *   "adapter_fold"    [HG_ADAPTER_FOLD]    1: adapter update folded into the block's own GEMMs; 0: separate up_proj GEMM
+ *   "chunk_rows"      [HG_CHUNK_ROWS]      rows per VAE / mlp_net / cache-logits chunk (>= 256; default 32768)
+ * Unknown keys and out-of-range values return HG_ERR_INVALID. */
+int hg_set_option(hg_ctx*, const char* key, int value);
+int hg_get_option(hg_ctx*, const char* key, int* value);
+
 /* ---- introspection for bench.py (no reference counterpart) --------------------------------- */
 int hg_workspace_bytes(hg_ctx*, uint64_t* bytes);
 /* Live per-kernel timing: from hg_profile_begin until hg_profile_end every launch of kernel kind `kind` (or, with
@@ -262,8 +274,7 @@ int hg_test_gemm(hg_ctx*, const float* a, const float* w, const float* bias, flo
  *              per-row partial statistics -> finalize_stats -> mr_out [M][2] = (mean - mu[m], rstd), mu_out [M] = mean
  *   epi 12     (duo, K >= 64): as 10 with the update scaled per column: x += (acc + bias) * scale[n]
  * All pointers are device fp32; a / w are rounded to fp16 inside; out2 comes back as fp32.  kernel: 0 dispatcher, 2 ring
- * family, 3 duo, 4 ring family with the context's stream-K workspace (epi 10: the 256x256 kernel deals K-tiles, not tiles,
- * to its workgroups when M / 256 * N / 256 >= 512 and K / 64 is a multiple of 4).  Unused pointers may be NULL. */
+ * family, 3 duo.  Unused pointers may be NULL. */
 int hg_test_gemm_ln(hg_ctx*, const float* a, const float* w, const float* bias, float* out, int M, int N, int K, int epi,
                     int kernel, const float* cs, const float* mr, const float* mu, const float* scale, float* out2,
                     float* mr_out, float* mu_out, void* stream);

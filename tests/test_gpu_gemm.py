@@ -195,41 +195,6 @@ def test_residual_epilogue_emits_copy_and_statistics(ctx, M, N, K):
             assert torch.equal(x, ref_bits[0]) and torch.equal(x16, ref_bits[1]), f"kernel {kernel}: bits differ from ring2's"
 
 
-@pytest.mark.parametrize("M,N,K", [(256 * 197, 768, 768), (256 * 197 - 100, 768, 3072), (256 * 171 + 9, 768, 512), (256 * 260, 512, 512)])
-def test_residual_epilogue_stream_k(ctx, M, N, K):
-    """Stream-K in the 256x256 residual kernel (hg_gemm_ring.hip): lanes of N/256 workgroups (one per column tile) walk equal,
-    contiguous shares of the row panels' K-tiles; a tile cut in two is finished by the workgroup that owns its head, starting
-    from the partner's dumped tail.  Same
-    contract as the whole-tile kernels; repeated launches give the same bits (fixed partition, fixed order of additions) and leave
-    the flags clear; tiles that are not cut agree bit for bit with ring2, cut ones to fp32 rounding of the K sum."""
-    g, a, w, bias = _operands(M, N, K, 11 * M + N + K)
-    x0 = torch.randn(M, N, device="cuda", generator=g) * 2 + torch.randn(M, 1, device="cuda", generator=g)
-    mu = x0.mean(1) + 0.05 * torch.randn(M, device="cuda", generator=g)
-    xr = x0 + a.half().float() @ w.half().float().t() + bias
-    mean = xr.mean(1)
-    rstd = 1.0 / torch.sqrt(xr.var(1, unbiased=False) + 1e-5)
-    scale = xr.abs().max().item()
-    whole = run_ln(ctx, a, w, bias, 10, 2, mu=mu, x0=x0)
-    first = None
-    for it in range(3):
-        x, x16, mr_out, mu_out = run_ln(ctx, a, w, bias, 10, 4, mu=mu, x0=x0)
-        assert (x - xr).abs().max().item() <= 2e-5 * scale, it
-        assert (x16 - (xr - mu[:, None]).half().float()).abs().max().item() <= 2e-3 * (xr - mu[:, None]).abs().max().item()
-        assert (mu_out - mean).abs().max().item() <= 1e-5 * scale
-        assert ((mr_out[:, 1] - rstd).abs() / rstd).max().item() <= 1e-4
-        first = (x, x16, mr_out, mu_out) if first is None else first
-        assert all(torch.equal(u, v) for u, v in zip((x, x16, mr_out, mu_out), first)), f"launch {it}: different bits"
-    # 256x256 blocks whose bits differ from the whole-tile kernel's = tiles cut in two: some (the shape qualifies), at most one
-    # per workgroup
-    Mp = (M + 255) // 256 * 256
-    diff = torch.zeros(Mp, N, dtype=torch.bool, device="cuda")
-    diff[:M] = first[0] != whole[0]
-    cut = diff.view(Mp // 256, 256, N // 256, 256).any(dim=3).any(dim=1).sum().item()
-    print(f"\nstream-K {M}x{N}x{K}: {cut} of {Mp // 256 * (N // 256)} tiles cut in two")
-    assert 0 < cut < 256
-    assert (first[0] - whole[0]).abs().max().item() <= 2e-6 * scale
-
-
 @pytest.mark.parametrize("M,N,K", [(197 * 12 + 5, 768, 64), (256 * 33 + 100, 768, 64), (2048 + 37, 768, 128), (1024 + 3, 768, 192),
                                    (4096 + 77, 768, 256)])
 def test_scaled_residual_epilogue_duo(ctx, M, N, K):

@@ -342,11 +342,10 @@ def test_vitb16_offset_residual_stream_vs_oracle(monkeypatch):
     img = torch.from_numpy(synth.crops(3, 224, seed=78))
     ref = co.encode_image(sd, img).numpy()
     m = build_model(synth.to_torch(raw)).to(dev())
-    for mode in ("1", "0"):
-        monkeypatch.setenv("HG_LN_FUSE", mode)
-        e = check(m.visual.forward_trace(img.to(dev()))[0], ref, what=f"offset stream, HG_LN_FUSE={mode}")
-        print(f"\noffset residual stream rel-L2 vs oracle, HG_LN_FUSE={mode}: {e:.3e}")
-    monkeypatch.delenv("HG_LN_FUSE")
+    for mode in (1, 0):
+        m.set_option("ln_fuse", mode)
+        e = check(m.visual.forward_trace(img.to(dev()))[0], ref, what=f"offset stream, ln_fuse={mode}")
+        print(f"\noffset residual stream rel-L2 vs oracle, ln_fuse={mode}: {e:.3e}")
 
 
 def test_vitb16_stress_outliers_vs_reference(g0, monkeypatch):
@@ -357,12 +356,12 @@ def test_vitb16_stress_outliers_vs_reference(g0, monkeypatch):
     g = dict(np.load(f"{G}/g8_stress.npz"))
     m = build_model(synth.to_torch(synth.stress_clip_state_dict(synth.VIT_B16, 0))).to(dev())
     img = torch.from_numpy(synth.crops(4, 224, seed=1234)).to(dev())
-    for mode in ("1", "0"):
-        monkeypatch.setenv("HG_LN_FUSE", mode)
+    for mode in (1, 0):
+        m.set_option("ln_fuse", mode)
         out = m.visual.forward_trace(img)[0]
-        e = check(out, g["encode_image"], what=f"stress encode_image HG_LN_FUSE={mode}")
-        print(f"\nstress encode_image rel-L2 vs reference, HG_LN_FUSE={mode}: {e:.3e}")
-    monkeypatch.delenv("HG_LN_FUSE")
+        e = check(out, g["encode_image"], what=f"stress encode_image ln_fuse={mode}")
+        print(f"\nstress encode_image rel-L2 vs reference, ln_fuse={mode}: {e:.3e}")
+    m.set_option("ln_fuse", 1)
     ids = ids_from_g0(g0, "hoi600", 64).to(dev())
     for trunc in (True, False):
         m.truncate_text = trunc
@@ -408,27 +407,29 @@ def test_batch256_invariance_and_determinism(fullA):
 
 
 def test_layernorm_folding_matches_separate_layernorm(fullA, g0, monkeypatch):
-    """The vision tower folds LayerNorm into its GEMMs for M >= 512; HG_LN_FUSE=0 selects the separate-LayerNorm
+    """The vision tower folds LayerNorm into its GEMMs for M >= 512; option ln_fuse = 0 selects the separate-LayerNorm
     path.  Both must sit within the parity tolerance of the reference and of each other; the text tower always
     uses the separate LayerNorm (its error budget is tighter)."""
     g = dict(np.load(f"{G}/g2_vitb16_image.npz"))
     img = torch.from_numpy(synth.crops(4, 224, seed=1234)).to(dev())
     ids = clip.tokenize(g0["obj81"]["text"]).to(dev())
     outs = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("HG_LN_FUSE", mode)
-        outs[mode] = (fullA.visual.forward_trace(img)[0], fullA.encode_text(ids).float())
-        e = check(outs[mode][0], g["encode_image"], what=f"encode_image HG_LN_FUSE={mode}")
-        print(f"\nencode_image rel-L2 vs reference, HG_LN_FUSE={mode}: {e:.3e}")
-    monkeypatch.delenv("HG_LN_FUSE")
-    assert not torch.equal(outs["1"][0], outs["0"][0]), "the switch did not change the executed path"
-    check(outs["1"][0], outs["0"][0].cpu().numpy(), what="folded vs separate LayerNorm (image)")
-    assert torch.equal(outs["1"][1], outs["0"][1]), "the text tower does not fold LayerNorm"
+    try:
+        for mode in (1, 0):
+            fullA.set_option("ln_fuse", mode)
+            outs[mode] = (fullA.visual.forward_trace(img)[0], fullA.encode_text(ids).float())
+            e = check(outs[mode][0], g["encode_image"], what=f"encode_image ln_fuse={mode}")
+            print(f"\nencode_image rel-L2 vs reference, ln_fuse={mode}: {e:.3e}")
+    finally:
+        fullA.set_option("ln_fuse", 1)
+    assert not torch.equal(outs[1][0], outs[0][0]), "the switch did not change the executed path"
+    check(outs[1][0], outs[0][0].cpu().numpy(), what="folded vs separate LayerNorm (image)")
+    assert torch.equal(outs[1][1], outs[0][1]), "the text tower does not fold LayerNorm"
 
 
 def test_last_block_on_class_rows_only_matches_full_last_block(fullA, g0, monkeypatch):
     """encode_image returns ln_post(x[:, 0]) @ proj, so after K and V the last block only needs the class-token row of
-    every crop; HG_LAST_BLOCK_ROW0=0 runs it on all 197 rows like the reference does.  Same result
+    every crop; option last_block_row0 = 0 runs it on all 197 rows like the reference does.  Same result
     within the parity tolerance, both within it of the reference, and the per-block trace agrees."""
     g = dict(np.load(f"{G}/g2_vitb16_image.npz"))
     torch.manual_seed(5)
@@ -436,24 +437,26 @@ def test_last_block_on_class_rows_only_matches_full_last_block(fullA, g0, monkey
     outs = {}
     ids = clip.tokenize(g0["obj81"]["text"]).to(dev())
     txt = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("HG_LAST_BLOCK_ROW0", mode)
-        outs[mode] = fullA.visual.forward_trace(img)
-        for trunc in (True, False):
-            fullA.truncate_text = trunc
-            txt[mode, trunc] = fullA.encode_text(ids).float()
-        fullA.truncate_text = True
-        e = check(outs[mode][0][:4], g["encode_image"], what=f"encode_image HG_LAST_BLOCK_ROW0={mode}")
-        print(f"\nencode_image rel-L2 vs reference, HG_LAST_BLOCK_ROW0={mode}: {e:.3e}")
-    monkeypatch.delenv("HG_LAST_BLOCK_ROW0")
-    assert not torch.equal(outs["1"][0], outs["0"][0]), "the switch did not change the executed path"
-    check(outs["1"][0], outs["0"][0].cpu().numpy(), what="class rows only vs full last block (embedding)")
-    assert torch.equal(outs["1"][1][:-1], outs["0"][1][:-1]), "blocks before the last one are untouched"
-    check(outs["1"][1][-1], outs["0"][1][-1].cpu().numpy(), what="class rows after the last block")
+    try:
+        for mode in (1, 0):
+            fullA.set_option("last_block_row0", mode)
+            outs[mode] = fullA.visual.forward_trace(img)
+            for trunc in (True, False):
+                fullA.truncate_text = trunc
+                txt[mode, trunc] = fullA.encode_text(ids).float()
+            fullA.truncate_text = True
+            e = check(outs[mode][0][:4], g["encode_image"], what=f"encode_image last_block_row0={mode}")
+            print(f"\nencode_image rel-L2 vs reference, last_block_row0={mode}: {e:.3e}")
+    finally:
+        fullA.set_option("last_block_row0", 1)
+    assert not torch.equal(outs[1][0], outs[0][0]), "the switch did not change the executed path"
+    check(outs[1][0], outs[0][0].cpu().numpy(), what="class rows only vs full last block (embedding)")
+    assert torch.equal(outs[1][1][:-1], outs[0][1][:-1]), "blocks before the last one are untouched"
+    check(outs[1][1][-1], outs[0][1][-1].cpu().numpy(), what="class rows after the last block")
     # the text tower (EOT rows) keeps the separate LayerNorm in both modes, and the 128x128 GEMM kernel of the dense
     # rows accumulates in the same order as the ring kernels: bit-identical
     for trunc in (True, False):
-        assert torch.equal(txt["1", trunc], txt["0", trunc]), f"text tower, EOT rows only (truncate={trunc})"
+        assert torch.equal(txt[1, trunc], txt[0, trunc]), f"text tower, EOT rows only (truncate={trunc})"
 
 
 def test_text_truncation_is_exact_selection(fullA, g0):
@@ -467,20 +470,30 @@ def test_text_truncation_is_exact_selection(fullA, g0):
     assert worst <= 2e-4, "running the causal tower on max(EOT)+1 positions must not change the EOT outputs"
 
 
-def test_stale_truncation_is_clamped_and_reported(fullA, g0, monkeypatch):
-    """a truncation length below max(EOT)+1 (a stale host memo) must neither read out of bounds nor stay
-    silent: EOT rows are clamped on the device, the NEXT text call raises, the one after works again."""
+def test_stale_truncation_is_clamped_and_reported(fullA, g0):
+    """a truncation length below max(EOT)+1 (a stale host memo: the tokens were rewritten through an alias that
+    bumps no version counter) must neither read out of bounds nor stay silent: EOT rows are clamped on the device, the stale
+    call's whole output is NaN, the NEXT text call raises AND drops the memo, the one after works again - with no help from the
+    test (the memo is poisoned directly, not monkeypatched back)."""
+    import weakref
     toks = ids_from_g0(g0, "hoi600", 16).to(dev())
     good = fullA.encode_text(toks).float().cpu()
     true_len = int(toks.argmax(-1).max()) + 1
-    monkeypatch.setattr(fullA, "_trunc_len", lambda *a, **k: true_len - 2)
-    bad = fullA.encode_text(toks).float().cpu()              # no crash; rows whose EOT was cut are wrong
-    assert torch.isfinite(bad).all()
-    monkeypatch.undo()
+    fullA._trunc_memo = (weakref.ref(toks), toks._version, toks.data_ptr(), true_len - 2)      # a stale memo for this very tensor
+    bad = fullA.encode_text(toks).float().cpu()              # no crash, no out-of-bounds read; loud: every value is NaN
+    assert torch.isnan(bad).all()
     with pytest.raises(RuntimeError, match="trunc"):
         fullA.encode_text(toks)
+    assert fullA._trunc_memo[0] is None                      # the failure dropped the stale memo
     again = fullA.encode_text(toks).float().cpu()
     assert torch.equal(again, good)
+    # the embeds entry point shares the memo and the flag
+    fullA._trunc_memo = (weakref.ref(toks), toks._version, toks.data_ptr(), true_len - 2)
+    emb = fullA.token_embedding(toks).float()
+    assert torch.isnan(fullA.encode_text_embeds(emb, toks)).all()
+    with pytest.raises(RuntimeError, match="trunc"):
+        fullA.encode_text_embeds(emb, toks)
+    assert torch.isfinite(fullA.encode_text_embeds(emb, toks)).all()
 
 
 def test_generation_pipeline_vs_oracle(g0):
@@ -519,3 +532,34 @@ def test_generation_pipeline_vs_oracle(g0):
     feat, target = sampler.sample(iterations=2)
     assert feat.shape == (2 * 20, 512) and target.shape == (40,) and torch.isfinite(feat).all()
     assert torch.equal(target.cpu(), torch.cat([tgt["hoi"].repeat(2), tgt["obj"].repeat(2)]))
+
+
+def test_eval_modules_work_with_grad_mode_on(fullA, g0):
+    """the suite runs under an autouse torch.no_grad(); users of ``build_model(...).eval()`` call with grad mode ON.
+    eval() modules (frozen or not) must pass the inference-only guard and give the same bits: image (fp32 and fp16 input),
+    text, variant C with adapters in eval(), and directly constructed VAE-family modules after .eval()."""
+    img = torch.from_numpy(synth.crops(2, 224, seed=1234)).to(dev())
+    ids = ids_from_g0(g0, "hoi600", 8).to(dev())
+    want_i, want_t = fullA.encode_image(img), fullA.encode_text(ids)
+    sd_c = synth.to_torch(synth.clip_state_dict(synth.VIT_B16, 0))
+    sd_c.update(synth.to_torch(synth.adapter_state_dict(synth.VIT_B16, 1)))
+    mc = build_model(sd_c, use_adapter=True).to(dev()).eval()
+    pri, mask = synth.priors(2, n=14, dim=64, n_pad=4, seed=99)
+    pri, mask = torch.from_numpy(pri).to(dev()), torch.from_numpy(mask).to(dev())
+    want_c = mc.visual(img, (pri, mask))
+    E, Gn = vae.Encoder().to(dev()), vae.Generator().to(dev())
+    x = vae.l2_normalize(torch.randn(16, 512, device=dev()))
+    with torch.enable_grad():
+        assert torch.is_grad_enabled()
+        fullA.eval()
+        assert torch.equal(fullA.encode_image(img), want_i)
+        assert torch.equal(fullA.encode_image(img.half()), fullA.encode_image(img.half()))
+        assert torch.equal(fullA.encode_text(ids), want_t)
+        got_c = mc.visual(img, (pri, mask))
+        assert all(torch.equal(a, b) for a, b in zip(got_c, want_c))
+        with pytest.raises(RuntimeError, match="train\\(\\) mode"):
+            E(x)                                      # a freshly constructed module is in train() mode with trainable weights
+        E.eval(); Gn.eval()
+        mean, logvar = E(x)
+        assert torch.isfinite(mean).all() and not mean.requires_grad
+        assert torch.isfinite(Gn(mean)).all()

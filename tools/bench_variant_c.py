@@ -26,7 +26,7 @@ def t(fn, reps=int(os.environ.get("REPS", 10))):
     for _ in range(reps): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps * 1e3
 
-os.environ["HG_LAST_BLOCK_ROW0"] = "0"
+mA.visual.set_option("last_block_row0", 0)      # every row of every block, like the headline
 a = t(lambda: mA.visual(img))
 c_prior = t(lambda: mC.visual(img, (pri, mask)))
 c_none = t(lambda: mC.visual(img, None))
