@@ -125,6 +125,7 @@ SIGNATURES = {
     "hg_test_gemm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "hg_test_gemm_ln": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hg_test_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "hg_test_gemm_hilo": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "hg_profile_begin": (_I, [_P, _I, _I]),
     "hg_profile_end": (_I, [_P, _P, _I, C.POINTER(C.c_int32)]),
 }

@@ -121,6 +121,7 @@ struct hg_ctx {
     Cache cache[HG_MAX_CACHE_SLOTS];
     // workspace (grow-only)
     Buf x, h, qkv, att, fc, head16, tok32, small, i32, ad32, ad16, adkv, mr, mu, muc, stats, pre, pretab, cx, ca, ch, cf, cq;
+    Buf xlo;             // low half of the residual stream while it is held as centre + hi + lo (GemmArgs::hl)
     int max_chunk_img = 256;
     int max_chunk_txt = 640;
     int max_chunk_rows = 32768;
@@ -130,6 +131,7 @@ struct hg_ctx {
     int opt_ln_fuse = 1;         // LayerNorm folded into the GEMMs where the shapes allow
     int opt_adapter_fuse = 1;    // ... also behind the instance adapters (variant C)
     int opt_adapter_fold = 1;    // adapter folded into the block's own QKV / out-proj GEMMs (0: separate up_proj GEMM)
+    int opt_stream_hilo = 1;     // residual stream as centre + hi + lo (two fp16 halves) between the folded blocks (0: fp32)
     // sticky device->host flag (host-mapped): set by clamp_eot when a caller-supplied text truncation was shorter than
     // max(EOT)+1 (a stale host memo); reported as HG_ERR_INVALID by the next text call
     int32_t* eot_flag = nullptr;
@@ -636,6 +638,36 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         HG_HIP(launch_layernorm_f32(x, pre_w, pre_b, x, M, D, s, pre_pos, pre_cls, L));
     }
     if (pre_w && trace) HG_HIP(launch_copy_rows(x, trace, n_seq, L, D, s));
+    // Residual stream as centre + hi + lo between the LayerNorm-emitting residual GEMMs (GemmArgs::hl; option stream_hilo):
+    // hi IS the centred fp16 copy those GEMMs write anyway, lo its fp16 remainder - 8 instead of 10 bytes per element through
+    // every such epilogue and a third fewer partial-line stores.  The first of them reads the fp32 stream (ln_pre wrote it),
+    // the last one writes fp32 again (the plain last c_proj / the class-rows path / ln_post read it); nothing in between
+    // touches x.  Variant A only (the adapters rewrite the stream), and only where the GEMMs run on gemm_ring2.
+    const bool row0_plan = row0_out && row0_env && !adapters;
+    const int n_rln = fuse ? (row0_plan ? 2 * ((int)blocks.size() - 1) : 2 * (int)blocks.size() - 1) : 0;
+    bool hilo = fuse && !adapters && c->opt_stream_hilo && n_rln >= 2;
+    if (hilo) {
+        GemmArgs r{};
+        r.M = M; r.N = D; r.ldc = D; r.K = D; r.lda = D;
+        hilo = gemm_ring2_ok(r);
+        r.K = 4 * D; r.lda = 4 * D;
+        hilo = hilo && gemm_ring2_ok(r);
+    }
+    if (hilo) {
+        int rc = ensure(c, c->xlo, gemm_lo_bytes(M, D));
+        if (!rc) rc = ensure(c, c->muc, rup(M, 256) * 4);
+        if (rc) return rc;
+        muc = (float*)c->muc.p;
+    }
+    int rln_i = 0;                  // index of the next LayerNorm-emitting residual GEMM
+    bool x_is_hilo = false;         // the stream currently lives in (h, xlo, muc), not in x
+    auto rln_args = [&](GemmArgs& g) {
+        if (!hilo) return;
+        g.hl = rln_i == 0 ? 1 : (rln_i == n_rln - 1 ? 3 : 2);
+        g.lo = (half_t*)c->xlo.p; g.muc = muc;
+        x_is_hilo = g.hl != 3;
+        ++rln_i;
+    };
     for (size_t i = 0; i < blocks.size(); ++i) {
         const BlockW& b = blocks[i];
         const int kcat = kmode[i];
@@ -705,6 +737,7 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         }
         if (fuse) {
             g.out2 = h; g.stats = stats; g.stats_ld = sld; g.mu = mu;
+            if (!kcat) rln_args(g);
             HG_HIP(gemm(c, EPI_RESID_LN_F32, g, s));
             HG_HIP(launch_finalize_stats(stats, mr, mu, M, sld, 64, s, muc));
         } else {
@@ -724,12 +757,17 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         g.A = fc; g.lda = 4 * D; g.W = b.w_proj; g.bias = b.b_proj; g.out = x; g.ldc = D; g.M = M; g.N = D; g.K = 4 * D;
         if (fuse && i + 1 < blocks.size()) {      // the last block is followed by ln_post / ln_final on selected rows
             g.out2 = h_of(i + 1); g.ld2 = ldh_of(i + 1); g.stats = stats; g.stats_ld = sld; g.mu = mu;
+            rln_args(g);
             HG_HIP(gemm(c, EPI_RESID_LN_F32, g, s));
             HG_HIP(launch_finalize_stats(stats, mr, mu, M, sld, 64, s, muc));
         } else {
             HG_HIP(gemm(c, EPI_BIAS_RESID_F32, g, s));
         }
-        if (trace) HG_HIP(launch_copy_rows(x, trace + (size_t)(i + 1) * trace_stride, n_seq, L, D, s));
+        if (trace) {
+            // (after finalize_stats muc is the centre the stream's hi / lo halves were written with)
+            if (x_is_hilo) HG_HIP(launch_copy_rows_hilo(h, (const half_t*)c->xlo.p, muc, trace + (size_t)(i + 1) * trace_stride, n_seq, L, D, s));
+            else HG_HIP(launch_copy_rows(x, trace + (size_t)(i + 1) * trace_stride, n_seq, L, D, s));
+        }
     }
     return HG_OK;
 }
@@ -847,7 +885,7 @@ hg_ctx* hg_create(int device) {
     }
     struct { const char* env; const char* key; } init[] = {{"HG_CHUNK_ROWS", "chunk_rows"}, {"HG_LAST_BLOCK_ROW0", "last_block_row0"},
                                                            {"HG_LN_FUSE", "ln_fuse"}, {"HG_ADAPTER_FUSE", "adapter_fuse"},
-                                                           {"HG_ADAPTER_FOLD", "adapter_fold"}};
+                                                           {"HG_ADAPTER_FOLD", "adapter_fold"}, {"HG_STREAM_HILO", "stream_hilo"}};
     for (auto& o : init)
         if (const char* e = getenv(o.env)) (void)hg_set_option(c, o.key, atoi(e));      // (out-of-range values are ignored)
     c->err.clear();
@@ -864,6 +902,7 @@ int hg_set_option(hg_ctx* c, const char* key, int value) {
     else if (k == "ln_fuse") c->opt_ln_fuse = value != 0;
     else if (k == "adapter_fuse") c->opt_adapter_fuse = value != 0;
     else if (k == "adapter_fold") c->opt_adapter_fold = value != 0;
+    else if (k == "stream_hilo") c->opt_stream_hilo = value != 0;
     else return fail(c, HG_ERR_INVALID, "unknown option '%s'", key);
     return HG_OK;
 }
@@ -876,6 +915,7 @@ int hg_get_option(hg_ctx* c, const char* key, int* value) {
     else if (k == "ln_fuse") *value = c->opt_ln_fuse;
     else if (k == "adapter_fuse") *value = c->opt_adapter_fuse;
     else if (k == "adapter_fold") *value = c->opt_adapter_fold;
+    else if (k == "stream_hilo") *value = c->opt_stream_hilo;
     else return fail(c, HG_ERR_INVALID, "unknown option '%s'", key);
     return HG_OK;
 }
@@ -891,7 +931,7 @@ void hg_destroy(hg_ctx* c) {
     for (auto& m : c->mlp) free_all(m.owned);
     for (auto& m : c->cache) free_all(m.owned);
     Buf* bufs[] = {&c->x, &c->h, &c->qkv, &c->att, &c->fc, &c->head16, &c->tok32, &c->small, &c->i32,
-                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq};
+                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq, &c->xlo};
     for (Buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
@@ -1062,6 +1102,45 @@ int hg_test_gemm_ln(hg_ctx* c, const float* a, const float* w, const float* bias
     return HG_OK;
 }
 
+int hg_test_gemm_hilo(hg_ctx* c, const float* a, const float* w, const float* bias, float* x, int M, int N, int K, int steps,
+                      int hilo, float* mu, float* out2, float* mr_out, void* stream) {
+    if (!c || !a || !w || !x || !mu || M <= 0 || steps < 1 || steps > 16) return HG_ERR_INVALID;
+    if (N % 256) return fail(c, HG_ERR_INVALID, "hg_test_gemm_hilo: N must be a multiple of 256");
+    hipStream_t s = (hipStream_t)stream;
+    HG_ON_DEVICE(c);
+    const size_t Mp = rup(M, 256);
+    const int sld = 4 * (N / 256);
+    int rc = ensure(c, c->h, Mp * K * 2);
+    if (!rc) rc = ensure(c, c->att, (size_t)N * K * 2);
+    if (!rc) rc = ensure(c, c->qkv, Mp * N * 2);
+    if (!rc) rc = ensure(c, c->mr, Mp * 2 * 4);
+    if (!rc) rc = ensure(c, c->mu, Mp * 4);
+    if (!rc) rc = ensure(c, c->muc, Mp * 4);
+    if (!rc) rc = ensure(c, c->stats, Mp * (size_t)sld * 2 * 4);
+    if (!rc) rc = ensure(c, c->xlo, gemm_lo_bytes(M, N));
+    if (rc) return rc;
+    HG_HIP(launch_f32_to_f16(a, (half_t*)c->h.p, (size_t)M * K, s));
+    HG_HIP(launch_f32_to_f16(w, (half_t*)c->att.p, (size_t)N * K, s));
+    HG_HIP(hipMemcpyAsync(c->mu.p, mu, (size_t)M * 4, hipMemcpyDeviceToDevice, s));
+    GemmArgs g{};
+    g.A = (half_t*)c->h.p; g.lda = K; g.W = (half_t*)c->att.p; g.bias = bias; g.M = M; g.N = N; g.K = K; g.ldc = N;
+    g.out = x; g.out2 = (half_t*)c->qkv.p; g.stats = (float*)c->stats.p; g.stats_ld = sld; g.mu = (const float*)c->mu.p;
+    g.lo = (half_t*)c->xlo.p; g.muc = (const float*)c->muc.p;
+    if (!gemm_ring2_ok(g)) return fail(c, HG_ERR_INVALID, "hg_test_gemm_hilo: shape not eligible for gemm_ring2");
+    for (int i = 0; i < steps; ++i) {
+        g.hl = (hilo && steps >= 2) ? (i == 0 ? 1 : (i == steps - 1 ? 3 : 2)) : 0;
+        ProfScope ps(c, s, EPI_RESID_LN_F32, M, N, K);
+        hipError_t e = launch_gemm_ring2(EPI_RESID_LN_F32, g, s);
+        ps.finish();
+        if (e != hipSuccess) return fail(c, HG_ERR_HIP, "test gemm (hi / lo) launch failed: %s", hipGetErrorString(e));
+        HG_HIP(launch_finalize_stats((const float*)c->stats.p, (float*)c->mr.p, (float*)c->mu.p, M, sld, 64, s, (float*)c->muc.p));
+    }
+    if (out2) HG_HIP(launch_f16_to_f32((const half_t*)c->qkv.p, out2, (size_t)M * N, s));
+    if (mr_out) HG_HIP(hipMemcpyAsync(mr_out, c->mr.p, (size_t)M * 2 * 4, hipMemcpyDeviceToDevice, s));
+    HG_HIP(hipMemcpyAsync(mu, c->mu.p, (size_t)M * 4, hipMemcpyDeviceToDevice, s));
+    return HG_OK;
+}
+
 int hg_test_attention(hg_ctx* c, const float* qkv, const float* q0, const int32_t* sel, int n_seq, int L, int heads,
                       int causal, float* out, void* stream) {
     if (!c || !qkv || !out || n_seq <= 0 || L < 1 || L > 224 || heads < 1) return HG_ERR_INVALID;
@@ -1124,7 +1203,7 @@ int hg_profile_end(hg_ctx* c, hg_prof_rec* recs, int max_recs, int32_t* n_recs) 
 int hg_workspace_bytes(hg_ctx* c, uint64_t* bytes) {
     if (!c || !bytes) return HG_ERR_INVALID;
     Buf* bufs[] = {&c->x, &c->h, &c->qkv, &c->att, &c->fc, &c->head16, &c->tok32, &c->small, &c->i32,
-                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq};
+                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq, &c->xlo};
     uint64_t t = 0;
     for (Buf* b : bufs) t += b->bytes;
     *bytes = t;

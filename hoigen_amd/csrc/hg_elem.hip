@@ -482,6 +482,30 @@ hipError_t launch_copy_rows(const float* x, float* out, int B, int row_stride, i
     hipLaunchKernelGGL(copy_rows_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, x, out, B, row_stride, D, gather);
     return hipGetLastError();
 }
+// row b * row_stride of a stream held as centre + hi + lo (GemmArgs::hl): hi row-major [*, D], lo in gemm_ring2's tile-fragment
+// order (tile 128 x 256; wave = (row % 64) / 32 * 4 + (col % 128) / 32; piece = (row / 64 % 2, col / 128 % 2, col / 16 % 2);
+// lane = (col % 16) / 4 * 16 + row % 16; inside the lane's 16 bytes: row tile (row % 32) / 16, then col % 4)
+__global__ void copy_rows_hilo_kernel(const half_t* __restrict__ hi, const half_t* __restrict__ lo, const float* __restrict__ muc,
+                                      float* __restrict__ out, int B, int row_stride, int D) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * D) return;
+    const int b = i / D, n = i - b * D;
+    const size_t m = (size_t)b * row_stride;
+    const int r = (int)(m & 127), cc = n & 255;
+    const size_t tile = (m >> 7) * (size_t)(D >> 8) + (n >> 8);
+    const int wave = ((r & 63) >> 5) * 4 + ((cc & 127) >> 5);
+    const int piece = (r >> 6) * 4 + (cc >> 7) * 2 + ((cc >> 4) & 1);
+    const int lane = ((cc & 15) >> 2) * 16 + (r & 15);
+    const size_t lo_i = (((tile * 8 + wave) * 8 + piece) * 64 + lane) * 8 + ((r & 31) >> 4) * 4 + (cc & 3);
+    out[i] = (muc[m] + (float)hi[m * D + n]) + (float)lo[lo_i];
+}
+hipError_t launch_copy_rows_hilo(const half_t* hi, const half_t* lo, const float* muc, float* out, int B, int row_stride, int D,
+                                 hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (D % 256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(copy_rows_hilo_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, hi, lo, muc, out, B, row_stride, D);
+    return hipGetLastError();
+}
 // first N columns of a [R, ld] matrix -> dense [R, N]
 __global__ void copy_cols_kernel(const float* __restrict__ x, int ld, float* __restrict__ out, int R, int N) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

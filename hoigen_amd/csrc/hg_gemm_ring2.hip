@@ -39,7 +39,12 @@ namespace hg {
 #define SEG_E(k) do {} while (0)
 #endif
 
-template <int EPI>
+// HL (EPI_RESID_LN_F32 only): how the residual stream is held on the way in / out (GemmArgs::hl): 0 fp32 / fp32, 1 fp32 /
+// hi + lo, 2 hi + lo / hi + lo, 3 hi + lo / fp32.  hi = the centred fp16 copy (row-major: the next GEMM's operand), lo = the
+// fp16 remainder in tile-fragment order: piece (ha, hb, g2) of a wave = this lane's two row tiles f = 0, 1 (2 x 8 B), 64 lanes
+// x 16 B contiguous - whole lines in, whole lines out.  8 instead of 10 bytes per element and 16 instead of 24 partial-line
+// store instructions per wave and tile.
+template <int EPI, int HL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int tiles_n, const int n_tiles,
                                                      const unsigned a_bytes, const int mode, const int gsz) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins (buffer resources, LDS DMA): host sees just the stub
@@ -61,8 +66,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
     constexpr bool RLN = (EPI == EPI_RESID_LN_F32);    // residual + fp16 copy + LayerNorm statistics for the next GEMM
     constexpr bool RESID = (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_SCALE_RESID_F32 || RLN);
     constexpr bool F16OUT = (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_BIAS_RELU_F16);
-    constexpr int E = F16OUT ? 8 : (RLN ? 28 : 16);    // epilogue store instructions per wave
-    constexpr int R = RESID ? (RLN ? 20 : 16) : 0;     // residual-row (+ row centre) prefetch loads per wave
+    static_assert(HL == 0 || EPI == EPI_RESID_LN_F32, "hi / lo stream: EPI_RESID_LN_F32 only");
+    constexpr bool IN_HL = (HL == 2 || HL == 3), OUT_HL = (HL == 1 || HL == 2);
+    constexpr int E = F16OUT ? 8 : (RLN ? (OUT_HL ? 20 : 28) : 16);    // epilogue store instructions per wave
+    constexpr int R = RESID ? (RLN ? (IN_HL ? 24 : 20) : 16) : 0;      // residual (+ row centre) prefetch loads per wave
     constexpr int BIAS_OFF = NST * STAGE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef HG_STAMPS
@@ -293,8 +300,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                 for (int f = 0; f < 2; ++f)
 #pragma unroll
                     for (int g2 = 0; g2 < 2; ++g2) acc[a][b][f][g2] = f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 xres[RESID ? 2 : 1][RESID ? 2 : 1][RESID ? 2 : 1][RESID ? 2 : 1];
+        f32x4 xres[RESID && !IN_HL ? 2 : 1][RESID && !IN_HL ? 2 : 1][RESID && !IN_HL ? 2 : 1][RESID && !IN_HL ? 2 : 1];
         float muv[RLN ? 2 : 1][RLN ? 2 : 1];          // EPI_RESID_LN: centre of this lane's rows for the fp16 copy
+        typedef unsigned u32x4_hl __attribute__((ext_vector_type(4)));
+        u32x4_hl xhi[IN_HL ? 2 : 1][IN_HL ? 2 : 1][IN_HL ? 2 : 1], xlo[IN_HL ? 2 : 1][IN_HL ? 2 : 1][IN_HL ? 2 : 1];   // [ha][hb][g2]
+        float mucv[IN_HL ? 2 : 1][IN_HL ? 2 : 1];     // centre the hi / lo being read were written with
+        // lo piece (ha, hb, g2) of this wave and tile: 64 lanes x 16 B
+        auto lo_ptr = [&](int tm_, int tn_, int ha, int hb, int g2) {
+            return p.lo + ((((size_t)tm_ * tiles_n + tn_) * 8 + wave) * 8 + (ha * 4 + hb * 2 + g2)) * 512 + lane * 8;
+        };
         // One K-tile.  KIND: 0 middle, 1 first of a tile (the previous epilogue's stores may be pending), 2 / 3 / 4 the
         // third-to-last, second-to-last and last K-tile of a tile: only there the refills (A at distance 2, W at
         // distance 3) and the waits depend on whether another tile follows.  K >= 256 keeps the kinds distinct.
@@ -309,7 +323,29 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
             read_W(st);
             if (KIND < 3 || more) issue_A(std::integral_constant<int, KIND == 3 ? 1 : 0>{});   // K-tile g+2 exists
             if constexpr (RESID && KIND == 4) {
-                {      // residual rows of this tile, needed by the epilogue one K-tile later
+                if constexpr (IN_HL) {      // hi (paired 16-byte pieces of the row-major copy), lo (this wave's own pieces), centres
+                    const int qq = lane >> 4;
+#pragma unroll
+                    for (int ha = 0; ha < 2; ++ha) {
+                        int mp = m0 + ha * 64 + wm * 32 + (lane & 15) + ((qq & 1) ? 16 : 0);
+                        mp = mp < p.M ? mp : p.M - 1;
+#pragma unroll
+                        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                            for (int g2 = 0; g2 < 2; ++g2) {
+                                xhi[ha][hb][g2] = *reinterpret_cast<const u32x4_hl*>(
+                                    p.out2 + (size_t)mp * p.ld2 + n0 + hb * 128 + wn * 32 + g2 * 16 + 4 * (qq & ~1));
+                                xlo[ha][hb][g2] = *reinterpret_cast<const u32x4_hl*>(lo_ptr(tm, tn, ha, hb, g2));
+                            }
+#pragma unroll
+                        for (int f = 0; f < 2; ++f) {
+                            int m = m0 + ha * 64 + wm * 32 + f * 16 + (lane & 15);
+                            m = m < p.M ? m : p.M - 1;
+                            muv[ha][f] = p.mu[m];
+                            mucv[ha][f] = p.muc[m];
+                        }
+                    }
+                } else {      // residual rows of this tile, needed by the epilogue one K-tile later
 #pragma unroll
                     for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
@@ -407,14 +443,35 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                     }
             }
         } else if constexpr (RLN) {
-            // x' = x + acc + bias (fp32, in place) ; x16 = fp16(x' - mu[row]) with mu = the row's previous mean (keeps
-            // the fp16 rounding relative to the row's spread, not to its offset) ; per row and per wave column group
-            // (64 columns) the pair (sum, sum of squared deviations from the group mean) for the next LayerNorm
+            // x' = x + acc + bias ; x16 = fp16(x' - mu[row]) with mu = the row's previous mean (keeps the fp16 rounding
+            // relative to the row's spread, not to its offset) ; per row and per wave column group (64 columns) the pair
+            // (sum, sum of squared deviations from the group mean) for the next LayerNorm.  The stream itself: fp32 in
+            // place, or (HL) centre + hi + lo with hi = that very copy and lo = fp16((x' - mu) - hi).
             half_t* out2 = p.out2;
             const int sg = tn * 4 + wn;                     // column group of this wave
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
             for (int ha = 0; ha < 2; ++ha) {
-                half4 h16[2][2][2];                         // [f][hb][g2]
+                half4 h16[2][2][2];                         // [f][hb][g2]: the new copy (hi)
+                half4 l16[OUT_HL ? 2 : 1][OUT_HL ? 2 : 1][OUT_HL ? 2 : 1];
+                half4 hin[IN_HL ? 2 : 1][IN_HL ? 2 : 1][IN_HL ? 2 : 1], lin[IN_HL ? 2 : 1][IN_HL ? 2 : 1][IN_HL ? 2 : 1];
+                if constexpr (IN_HL) {
+                    // the copy was stored with the row tiles f = 0, 1 paired through v_permlane16_swap (below); the same
+                    // exchange gives every lane its own two row tiles back; the lo piece holds them side by side
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                        for (int g2 = 0; g2 < 2; ++g2) {
+                            const u32x4_hl o = xhi[ha][hb][g2], l = xlo[ha][hb][g2];
+                            const auto s0 = __builtin_amdgcn_permlane16_swap(o[0], o[2], false, false);
+                            const auto s1 = __builtin_amdgcn_permlane16_swap(o[1], o[3], false, false);
+                            hin[0][hb][g2] = __builtin_bit_cast(half4, u32x2{(unsigned)s0[0], (unsigned)s1[0]});
+                            hin[1][hb][g2] = __builtin_bit_cast(half4, u32x2{(unsigned)s0[1], (unsigned)s1[1]});
+                            lin[0][hb][g2] = __builtin_bit_cast(half4, u32x2{l[0], l[1]});
+                            lin[1][hb][g2] = __builtin_bit_cast(half4, u32x2{l[2], l[3]});
+                        }
+                }
 #pragma unroll
                 for (int f = 0; f < 2; ++f) {
                     const int m = m0 + ha * 64 + wm * 32 + f * 16 + (lane & 15);
@@ -425,13 +482,27 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
 #pragma unroll
                         for (int g2 = 0; g2 < 2; ++g2) {
                             const int n = n0 + hb * 128 + wn * 32 + g2 * 16 + 4 * q;
-                            v[hb][g2] = xres[ha][hb][f][g2] +
-                                        (acc[ha][hb][f][g2] + *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + n * 4));
-                            sum += (v[hb][g2][0] + v[hb][g2][1]) + (v[hb][g2][2] + v[hb][g2][3]);
-                            if (INTERIOR || m < p.M)
-                                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v[hb][g2];
+                            f32x4 xin;
+                            if constexpr (IN_HL) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) h16[f][hb][g2][e] = (half_t)(v[hb][g2][e] - muv[ha][f]);
+                                for (int e = 0; e < 4; ++e)
+                                    xin[e] = (mucv[ha][f] + (float)hin[f][hb][g2][e]) + (float)lin[f][hb][g2][e];
+                            } else {
+                                xin = xres[ha][hb][f][g2];
+                            }
+                            v[hb][g2] = xin + (acc[ha][hb][f][g2] + *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + n * 4));
+                            sum += (v[hb][g2][0] + v[hb][g2][1]) + (v[hb][g2][2] + v[hb][g2][3]);
+                            if constexpr (!OUT_HL) {
+                                if (INTERIOR || m < p.M)
+                                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v[hb][g2];
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float d = v[hb][g2][e] - muv[ha][f];
+                                const half_t hh = (half_t)d;
+                                h16[f][hb][g2][e] = hh;
+                                if constexpr (OUT_HL) l16[f][hb][g2][e] = (half_t)(d - (float)hh);
+                            }
                         }
                     sum = sum_rows(sum);
                     const float gm = sum * (1.0f / 64.0f);
@@ -459,13 +530,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
 #pragma unroll
                     for (int g2 = 0; g2 < 2; ++g2) {
                         const int nb = n0 + hb * 128 + wn * 32 + g2 * 16;
-                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                         const u32x2 ux = __builtin_bit_cast(u32x2, h16[0][hb][g2]), uy = __builtin_bit_cast(u32x2, h16[1][hb][g2]);
                         const auto s0 = __builtin_amdgcn_permlane16_swap(ux[0], uy[0], false, false);
                         const auto s1 = __builtin_amdgcn_permlane16_swap(ux[1], uy[1], false, false);
                         const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
                         if (INTERIOR || m < p.M) *reinterpret_cast<u32x4*>(out2 + (size_t)m * p.ld2 + nb + 4 * (q & ~1)) = o;
+                        if constexpr (OUT_HL) {      // the remainder: this lane's two row tiles side by side, the wave's piece contiguous
+                            const u32x2 lx = __builtin_bit_cast(u32x2, l16[0][hb][g2]), ly = __builtin_bit_cast(u32x2, l16[1][hb][g2]);
+                            *reinterpret_cast<u32x4*>(lo_ptr(tm, tn, ha, hb, g2)) = u32x4{lx[0], lx[1], ly[0], ly[1]};
+                        }
                     }
             }
         } else {
@@ -510,7 +583,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
 #endif
 }
 
-template <int EPI>
+template <int EPI, int HL = 0>
 static hipError_t launch_ring2_t(const GemmArgs& a, hipStream_t s) {
     constexpr int RING = 3 * 49152;
     const int LDS = RING + a.N * 4;
@@ -522,7 +595,7 @@ static hipError_t launch_ring2_t(const GemmArgs& a, hipStream_t s) {
     int& n_cu = n_cu_d[dev_i];
     if (!attr_set) {
         n_cu = 256;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring2<EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring2<EPI, HL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         int dev = 0;
@@ -566,7 +639,7 @@ static hipError_t launch_ring2_t(const GemmArgs& a, hipStream_t s) {
         hipMemsetAsync(d, 0, n * 8, s);
         GemmArgs b = a;
         b.dbg = d;
-        hipLaunchKernelGGL((gemm_ring2<EPI>), dim3(grid), dim3(512), LDS, s, b, tiles_n, n_tiles, (unsigned)a_bytes, mode, gsz);
+        hipLaunchKernelGGL((gemm_ring2<EPI, HL>), dim3(grid), dim3(512), LDS, s, b, tiles_n, n_tiles, (unsigned)a_bytes, mode, gsz);
         hipStreamSynchronize(s);
         unsigned long long* h = (unsigned long long*)malloc(n * 8);
         hipMemcpy(h, d, n * 8, hipMemcpyDeviceToHost);
@@ -586,7 +659,7 @@ static hipError_t launch_ring2_t(const GemmArgs& a, hipStream_t s) {
         return hipGetLastError();
     }
 #endif
-    hipLaunchKernelGGL((gemm_ring2<EPI>), dim3(grid), dim3(512), LDS, s, a, tiles_n, n_tiles, (unsigned)a_bytes, mode, gsz);
+    hipLaunchKernelGGL((gemm_ring2<EPI, HL>), dim3(grid), dim3(512), LDS, s, a, tiles_n, n_tiles, (unsigned)a_bytes, mode, gsz);
     return hipGetLastError();
 }
 
@@ -606,7 +679,15 @@ hipError_t launch_gemm_ring2(int epi, const GemmArgs& a_in, hipStream_t s) {
         case EPI_PATCH_F32: return launch_ring2_t<EPI_PATCH_F32>(a, s);
         case EPI_BIAS_RELU_F32: return launch_ring2_t<EPI_BIAS_RELU_F32>(a, s);
         case EPI_SCALE_RESID_F32: return launch_ring2_t<EPI_SCALE_RESID_F32>(a, s);
-        case EPI_RESID_LN_F32: return launch_ring2_t<EPI_RESID_LN_F32>(a, s);
+        case EPI_RESID_LN_F32:
+            if (a.hl && (!a.lo || !a.mu || ((a.hl == 2 || a.hl == 3) && !a.muc) || a.ld2 != a.ldc)) return hipErrorInvalidValue;
+            switch (a.hl) {
+                case 0: return launch_ring2_t<EPI_RESID_LN_F32, 0>(a, s);
+                case 1: return launch_ring2_t<EPI_RESID_LN_F32, 1>(a, s);
+                case 2: return launch_ring2_t<EPI_RESID_LN_F32, 2>(a, s);
+                case 3: return launch_ring2_t<EPI_RESID_LN_F32, 3>(a, s);
+                default: return hipErrorInvalidValue;
+            }
         default: return hipErrorInvalidValue;
     }
 }

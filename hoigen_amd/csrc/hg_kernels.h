@@ -54,7 +54,17 @@ struct GemmArgs {
     void* out_hi = nullptr;
     int n_split = 0;                     // multiple of 16
     unsigned long long* dbg = nullptr;   // diagnostics: s_memtime totals (HG_STAMPS build), normally null
+    // EPI_RESID_LN with the residual stream held as TWO fp16 halves instead of fp32 (gemm_ring2 only; DESIGN.md 4 "hi / lo"):
+    //   x = centre + hi + lo,   hi = fp16(x - centre) = the centred copy `out2` the next GEMM reads anyway,
+    //   lo = fp16((x - centre) - hi) in `lo` (tile-fragment order: only this kernel family reads it, 16 B per lane, whole lines)
+    // hl: 0 fp32 in / fp32 out (`out`), 1 fp32 in / hi+lo out, 2 hi+lo in / hi+lo out, 3 hi+lo in / fp32 out (+ copy as always).
+    // muc [M] = the centre the hi / lo being READ were written with (finalize_stats' muc); mu = the centre to write with.
+    int hl = 0;
+    half_t* lo = nullptr;
+    const float* muc = nullptr;
 };
+// bytes of the `lo` buffer for M rows x N columns (whole 128 x 256 tiles)
+inline size_t gemm_lo_bytes(int M, int N) { return (size_t)((M + 127) / 128) * (N / 256) * 65536; }
 
 // Requirements: N % 128 == 0, K % 64 == 0, A readable for rows < M, 16-byte aligned rows.
 // A must be allocated with its row count padded to a multiple of 256 (the ring kernel's DMA reads whole
@@ -127,6 +137,9 @@ hipError_t launch_split_global_local(const float* tok, float* glob, float* local
                                      hipStream_t s);
 hipError_t launch_copy_rows(const float* x, float* out, int B, int row_stride, int D, hipStream_t s,
                             const int32_t* gather = nullptr);   // row b*row_stride (+ gather[b])
+// the same from a stream held as centre + hi + lo (GemmArgs::hl): hi [*, D] row-major, lo in gemm_ring2's tile-fragment order
+hipError_t launch_copy_rows_hilo(const half_t* hi, const half_t* lo, const float* muc, float* out, int B, int row_stride, int D,
+                                 hipStream_t s);
 // first N columns of a [R, ld] fp32 matrix -> dense [R, N]
 hipError_t launch_copy_cols(const float* x, int ld, float* out, int R, int N, hipStream_t s);
 // ---- LayerNorm folding support (DESIGN.md §4 "LayerNorm folded into the GEMMs")

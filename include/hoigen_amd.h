@@ -238,6 +238,8 @@ int hg_vae_loss(hg_ctx*, const float* recon, const float* x, const float* mean, 
  *   "ln_fuse"         [HG_LN_FUSE]         1: LayerNorm folded into the GEMMs (vision tower, M >= 512); 0: separate kernels
  *   "adapter_fuse"    [HG_ADAPTER_FUSE]    1: ... also around the instance adapters of variant C
  *   "adapter_fold"    [HG_ADAPTER_FOLD]    1: adapter update folded into the block's own GEMMs; 0: separate up_proj GEMM
+ *   "stream_hilo"     [HG_STREAM_HILO]     1: between the LayerNorm-folded blocks of variant A the residual stream is held as
+ *                      centre + two fp16 halves (the centred copy the GEMMs read + its remainder); 0: as fp32 throughout
  *   "chunk_rows"      [HG_CHUNK_ROWS]      rows per VAE / mlp_net / cache-logits chunk (>= 256; default 32768)
  * Unknown keys and out-of-range values return HG_ERR_INVALID. */
 int hg_set_option(hg_ctx*, const char* key, int value);
@@ -278,6 +280,12 @@ int hg_test_gemm(hg_ctx*, const float* a, const float* w, const float* bias, flo
 int hg_test_gemm_ln(hg_ctx*, const float* a, const float* w, const float* bias, float* out, int M, int N, int K, int epi,
                     int kernel, const float* cs, const float* mr, const float* mu, const float* scale, float* out2,
                     float* mr_out, float* mu_out, void* stream);
+/* Test hook for the residual stream held as centre + hi + lo: `steps` (2..16) residual updates
+ * x += a W^T + bias in a row through gemm_ring2 + finalize_stats, the stream between them as two fp16 halves (hilo = 1: the
+ * first update reads fp32 x, the last writes fp32 x) or as fp32 throughout (hilo = 0).  x [M,N] and mu [M] (centre of the
+ * first copy in, last mean out) are read-modify-written; out2 = the last centred copy (fp32), mr_out [M][2]; both may be NULL. */
+int hg_test_gemm_hilo(hg_ctx*, const float* a, const float* w, const float* bias, float* x, int M, int N, int K, int steps,
+                      int hilo, float* mu, float* out2, float* mr_out, void* stream);
 /* Test hook for the attention kernels (clipnet/model.py:171,181-183: the SDPA inside nn.MultiheadAttention, head_dim
  * 64): qkv [n_seq*L, 3*heads*64] fp32 on the device (rounded to fp16 inside).  q0 == NULL: full attention, out
  * [n_seq*L, heads*64].  q0 != NULL: [n_seq, heads*64] queries of ONE row per sequence (row sel[seq], device int32, or

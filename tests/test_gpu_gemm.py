@@ -230,3 +230,42 @@ def test_duo_short_k(ctx, M, N, K, epi):
     assert (got1 - want).abs().max().item() <= (3e-3 if epi == 0 else 2e-5) * want.abs().max().item()
     for _ in range(3):
         assert torch.equal(got1, run(ctx, a, w, bias, epi, 3, out0))
+
+
+@pytest.mark.parametrize("M,N,K", [(197 * 12 + 5, 768, 768), (128 * 41, 768, 3072), (256 * 33 + 100, 768, 256), (128 * 394, 768, 768)])
+def test_residual_stream_as_two_fp16_halves(ctx, M, N, K):
+    """GemmArgs::hl (DESIGN.md 4): five residual updates in a row with the stream held as centre + hi + lo between them (the first
+    reads fp32, the last writes fp32) against the same five updates on an fp32 stream: the final rows agree to fp32 rounding
+    (hi + lo carry 22 bits of x - centre), the last copy and statistics agree, repeated runs are bit-identical; rows with a
+    large common offset and 30x outlier columns included."""
+    g, a, w, bias = _operands(M, N, K, 13 * M + N + K)
+    x0 = torch.randn(M, N, device="cuda", generator=g) * 2 + 8 * torch.randn(M, 1, device="cuda", generator=g)
+    x0[:, 5::97] *= 30.0
+    mu0 = x0.mean(1) + 0.05 * torch.randn(M, device="cuda", generator=g)
+    p = lambda t: t.data_ptr()
+
+    def run(hilo):
+        x, mu = x0.clone(), mu0.clone()
+        out2, mr = torch.empty(M, N, device="cuda"), torch.empty(M, 2, device="cuda")
+        rc = _lib.lib().hg_test_gemm_hilo(ctx, p(a), p(w), p(bias), p(x), M, N, K, 5, hilo, p(mu), p(out2), p(mr), None)
+        assert rc == 0, _lib.lib().hg_last_error(ctx)
+        torch.cuda.synchronize()
+        return x, mu, out2, mr
+
+    f32 = run(0)
+    upd = a.half().float() @ w.half().float().t() + bias
+    want = x0 + 5 * upd
+    scale = want.abs().max().item()
+    assert (f32[0] - want).abs().max().item() <= 1e-5 * scale
+    hl = run(1)
+    again = run(1)
+    assert all(torch.equal(u, v) for u, v in zip(hl, again)), "same inputs, different bits"
+    assert torch.isfinite(hl[0]).all()
+    # against the fp32 stream: per element relative to the row's spread about its centre (what the halves are scaled to)
+    spread = (want - want.mean(1, keepdim=True)).abs().amax(1, keepdim=True)
+    err = ((hl[0] - f32[0]).abs() / spread).max().item()
+    print(f"\\nhi/lo stream vs fp32 stream after 5 updates: max |diff| / row spread = {err:.2e}")
+    assert err <= 4e-6
+    assert (hl[1] - f32[1]).abs().max().item() <= 1e-5 * scale                      # mean
+    assert ((hl[3][:, 1] - f32[3][:, 1]).abs() / f32[3][:, 1]).max().item() <= 1e-4   # rstd
+    assert (hl[2] - f32[2]).abs().max().item() <= 2e-3 * spread.max().item()          # last centred copy (fp16 grid)

@@ -451,7 +451,10 @@ def test_last_block_on_class_rows_only_matches_full_last_block(fullA, g0, monkey
         fullA.set_option("last_block_row0", 1)
     assert not torch.equal(outs[1][0], outs[0][0]), "the switch did not change the executed path"
     check(outs[1][0], outs[0][0].cpu().numpy(), what="class rows only vs full last block (embedding)")
-    assert torch.equal(outs[1][1][:-1], outs[0][1][:-1]), "blocks before the last one are untouched"
+    assert torch.equal(outs[1][1][:-2], outs[0][1][:-2]), "blocks before the last two are untouched"
+    # the stream leaves its hi + lo form one residual GEMM earlier when the last block runs on the class rows:
+    # after the second-to-last block the two arrangements hold the same rows to the 22 bits the halves carry
+    check(outs[1][1][-2], outs[0][1][-2].cpu().numpy(), tol=2e-6, what="class rows after the second-to-last block")
     check(outs[1][1][-1], outs[0][1][-1].cpu().numpy(), what="class rows after the last block")
     # the text tower (EOT rows) keeps the separate LayerNorm in both modes, and the 128x128 GEMM kernel of the dense
     # rows accumulates in the same order as the ring kernels: bit-identical
@@ -563,3 +566,32 @@ def test_eval_modules_work_with_grad_mode_on(fullA, g0):
         mean, logvar = E(x)
         assert torch.isfinite(mean).all() and not mean.requires_grad
         assert torch.isfinite(Gn(mean)).all()
+
+
+def test_residual_stream_as_two_fp16_halves_matches_fp32_stream(fullA):
+    """Option stream_hilo (default on): between the LayerNorm-folded blocks of variant A the residual stream
+    lives as centre + hi + lo (two fp16 halves, 22 bits of x - centre) instead of fp32.  Both arrangements sit within the parity
+    tolerance of the reference; against each other the embeddings and the per-block class-token trace differ by rounding noise
+    only; with the class-rows-only last block and with every row."""  # noqa: D400
+    g = dict(np.load(f"{G}/g2_vitb16_image.npz"))
+    torch.manual_seed(11)
+    img = torch.cat([torch.from_numpy(synth.crops(4, 224, seed=1234)).to(dev()), torch.randn(20, 3, 224, 224, device=dev())])
+    try:
+        for row0 in (1, 0):
+            fullA.set_option("last_block_row0", row0)
+            outs = {}
+            for mode in (1, 0):
+                fullA.set_option("stream_hilo", mode)
+                outs[mode] = fullA.visual.forward_trace(img)
+                e = check(outs[mode][0][:4], g["encode_image"], what=f"encode_image stream_hilo={mode} row0={row0}")
+                print(f"\nencode_image rel-L2 vs reference, stream_hilo={mode}, last_block_row0={row0}: {e:.3e}")
+            assert not torch.equal(outs[1][1], outs[0][1]), "the switch did not change the executed path"
+            # (a 1e-7 difference in the stream flips fp16 roundings of the operand copies downstream: the two arrangements are two
+            # realisations of the same fp16 rounding noise, each 3e-4 from the reference - against each other they sit at that level too)
+            check(outs[1][0], outs[0][0].cpu().numpy(), what="hi/lo stream vs fp32 stream (embedding)")
+            # early blocks: before the roundings decorrelate the stream itself agrees to the 22 bits the halves carry
+            check(outs[1][1][1], outs[0][1][1].cpu().numpy(), tol=1e-5, what="class rows after block 1, hi/lo vs fp32 stream")
+            check(outs[1][1], outs[0][1].cpu().numpy(), what="class-token trace, hi/lo vs fp32 stream")
+    finally:
+        fullA.set_option("stream_hilo", 1)
+        fullA.set_option("last_block_row0", 1)
