@@ -51,7 +51,7 @@ KIND_NAMES = {0: "gemm bias->f16", 1: "gemm bias+QuickGELU->f16", 2: "gemm bias+
               8: "gemm_ring<LN-fold bias->f16>", 9: "gemm_ring<LN-fold bias+QuickGELU->f16>",
               10: "gemm_ring2<residual + x16 + row stats>", 11: "gemm adapter down_proj", 12: "gemm_duo<adapter up_proj>",
               13: "gemm_ring<VAE mean|log_var + reparameterise>", 14: "gemm_duo<adapter up_proj, fp16 copy only>",
-              100: "attention_kernel"}
+              100: "attention_kernel", 101: "qkv_attn_kernel<in_proj + attention, q k v in LDS>"}
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -331,6 +331,10 @@ def kernel_row(kind, M, N, K):
     if kind == 100:                       # attention: M sequences of N tokens, K heads of 64
         rows, D = M * N, K * 64
         return f"attention (L={N}, {K} heads)", 4.0 * M * K * N * N * 64, rows * 3 * D * 2 + rows * D * 2
+    if kind == 101:                       # in_proj + attention in one kernel (q, k, v stay in LDS): x16 in, W once, att out
+        rows, D = M * N, K * 64
+        return (f"in_proj + attention fused (L={N}, {K} heads)", 2.0 * rows * 3 * D * D + 4.0 * M * K * N * N * 64,
+                rows * D * 2 + 3 * D * D * 2 + rows * D * 2)
     fl = 2.0 * M * N * K
     w = N * K * 2
     if kind in (0, 8):

@@ -88,7 +88,7 @@ class hg_prof_rec(C.Structure):
     _fields_ = [("kind", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("ms", C.c_float)]
 
 
-HG_PROF_OFF, HG_PROF_ALL, HG_PROF_ATTENTION = -1, -2, 100
+HG_PROF_OFF, HG_PROF_ALL, HG_PROF_ATTENTION, HG_PROF_QKV_ATTN = -1, -2, 100, 101
 
 _P = C.c_void_p
 _I = C.c_int
@@ -125,6 +125,7 @@ SIGNATURES = {
     "hg_test_gemm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "hg_test_gemm_ln": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hg_test_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "hg_test_qkv_attn": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "hg_test_gemm_hilo": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "hg_profile_begin": (_I, [_P, _I, _I]),
     "hg_profile_end": (_I, [_P, _P, _I, C.POINTER(C.c_int32)]),

@@ -18,6 +18,8 @@
 #include <string>
 #include <vector>
 
+#include <algorithm>
+
 #include "../../include/hoigen_amd.h"
 #include "hg_kernels.h"
 
@@ -37,6 +39,10 @@ struct BlockW {
     // b' = b + W beta;  LN(x) W^T + b = rstd * (x16 W'^T - mean * cs) + b'
     half_t *wf_qkv, *wf_fc;
     float *cs_qkv, *bf_qkv, *cs_fc, *bf_fc;
+    // wf_qkv / bf_qkv / cs_qkv once more in the order the fused in_proj + attention kernel streams them (hg_qkv_attn.hip:
+    // MFMA fragments per head pair); null when the width does not qualify
+    half_t* wp_qkv;
+    float* bcs_qkv;
 };
 
 struct AdapterW {
@@ -132,6 +138,9 @@ struct hg_ctx {
     int opt_adapter_fuse = 1;    // ... also behind the instance adapters (variant C)
     int opt_adapter_fold = 1;    // adapter folded into the block's own QKV / out-proj GEMMs (0: separate up_proj GEMM)
     int opt_stream_hilo = 1;     // residual stream as centre + hi + lo (two fp16 halves) between the folded blocks (0: fp32)
+    int opt_qkv_attn = 1;        // in_proj + attention as one kernel, q / k / v kept in LDS (vision tower, folded blocks; 0: two kernels)
+    int opt_qkv_attn_min_seq = 64;   // ... from this many sequences per call on (fewer: not enough items to fill the chip)
+    int opt_qkv_attn_gsz = 0;    // head pairs per XCD group of that kernel (0 = all)
     // sticky device->host flag (host-mapped): set by clamp_eot when a caller-supplied text truncation was shorter than
     // max(EOT)+1 (a stale host memo); reported as HG_ERR_INVALID by the next text call
     int32_t* eot_flag = nullptr;
@@ -305,6 +314,12 @@ int load_blocks(hg_ctx* c, std::vector<void*>& owned, const hg_block_weights* sr
         if (rc) return rc < 0 ? rc : HG_ERR_OOM;
         HG_HIP(launch_fold_ln(b.w_qkv, b.ln1_w, b.ln1_b, b.b_qkv, b.wf_qkv, b.cs_qkv, b.bf_qkv, 3 * D, D, 0));
         HG_HIP(launch_fold_ln(b.w_fc, b.ln2_w, b.ln2_b, b.b_fc, b.wf_fc, b.cs_fc, b.bf_fc, 4 * D, D, 0));
+        if (qkv_attn_ok(1, 197, D, D / 64, D)) {      // (heads = width / 64 in every CLIP tower; L is checked per call)
+            keep_first(rc, dev_alloc(c, owned, (size_t)3 * D * D * 2, (void**)&b.wp_qkv));
+            keep_first(rc, dev_alloc(c, owned, (size_t)(D / 128) * 768 * 4, (void**)&b.bcs_qkv));
+            if (rc) return rc < 0 ? rc : HG_ERR_OOM;
+            HG_HIP(launch_pack_qkv(b.wf_qkv, b.bf_qkv, b.cs_qkv, b.wp_qkv, b.bcs_qkv, D, D / 64, 0));
+        }
     }
     return HG_OK;
 }
@@ -659,6 +674,10 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         if (rc) return rc;
         muc = (float*)c->muc.p;
     }
+    // blocks whose in_proj and attention run as one kernel (option qkv_attn): folded LayerNorm, no adapter in the block's
+    // GEMMs, a sequence per row tile (192 < L <= 208), enough sequences to fill the chip
+    const bool qa_on = fuse && !causal && c->opt_qkv_attn && n_seq >= c->opt_qkv_attn_min_seq && qkv_attn_ok(n_seq, L, D, heads, D);
+    auto qa_block = [&](size_t i, bool row0_last_blk) { return qa_on && !row0_last_blk && kmode[i] == 0 && blocks[i].wp_qkv != nullptr; };
     int rln_i = 0;                  // index of the next LayerNorm-emitting residual GEMM
     bool x_is_hilo = false;         // the stream currently lives in (h, xlo, muc), not in x
     auto rln_args = [&](GemmArgs& g) {
@@ -690,6 +709,14 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
             g.A = att; g.lda = D + 64; g.K = D + 64;
             g.W = c->vit.adapters[i].fold[ac->priors ? 0 : 1].wq_cat; g.bias = b.bf_qkv; g.cs = b.cs_qkv; g.mr = mr;
             HG_HIP(gemm(c, EPI_LN_BIAS_F16, g, s));
+        } else if (fuse && qa_block(i, row0_last)) {
+            // in_proj + attention in one kernel: q, k, v stay in LDS (hg_qkv_attn.hip); bit-identical to the two kernels below
+            QkvAttnArgs qa{};
+            qa.x16 = h; qa.lda = D; qa.wp = b.wp_qkv; qa.bcs = b.bcs_qkv; qa.mr = mr; qa.out = att; qa.ldo = D;
+            qa.n_seq = n_seq; qa.L = L; qa.D = D; qa.heads = heads; qa.gsz = c->opt_qkv_attn_gsz;
+            qa.a_bytes = (unsigned)(rup(M, 256) * (size_t)D * 2);
+            ProfScope ps(c, s, HG_PROF_QKV_ATTN, n_seq, L, heads);
+            HG_HIP(launch_qkv_attn(qa, s));
         } else if (fuse) {
             g.W = b.wf_qkv + qoff * D; g.bias = b.bf_qkv + qoff; g.cs = b.cs_qkv + qoff; g.mr = mr;
             HG_HIP(gemm(c, EPI_LN_BIAS_F16, g, s));
@@ -729,7 +756,7 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
             *row0_out = cx;
             break;
         }
-        HG_HIP(attention(c, qkv, att, n_seq, L, heads, causal, s, kcat ? D + 64 : 0));
+        if (!(fuse && qa_block(i, row0_last))) HG_HIP(attention(c, qkv, att, n_seq, L, heads, causal, s, kcat ? D + 64 : 0));
         g = GemmArgs{};
         g.A = att; g.lda = D; g.W = b.w_out; g.bias = b.b_out; g.out = x; g.ldc = D; g.M = M; g.N = D; g.K = D;
         if (kcat == 2) {      // x += [att | e] [W_out | Q]^T + b_out: the adapter's update rides along
@@ -885,7 +912,9 @@ hg_ctx* hg_create(int device) {
     }
     struct { const char* env; const char* key; } init[] = {{"HG_CHUNK_ROWS", "chunk_rows"}, {"HG_LAST_BLOCK_ROW0", "last_block_row0"},
                                                            {"HG_LN_FUSE", "ln_fuse"}, {"HG_ADAPTER_FUSE", "adapter_fuse"},
-                                                           {"HG_ADAPTER_FOLD", "adapter_fold"}, {"HG_STREAM_HILO", "stream_hilo"}};
+                                                           {"HG_ADAPTER_FOLD", "adapter_fold"}, {"HG_STREAM_HILO", "stream_hilo"},
+                                                           {"HG_QKV_ATTN", "qkv_attn"}, {"HG_QKV_ATTN_MIN_SEQ", "qkv_attn_min_seq"},
+                                                           {"HG_QKV_ATTN_GSZ", "qkv_attn_gsz"}};
     for (auto& o : init)
         if (const char* e = getenv(o.env)) (void)hg_set_option(c, o.key, atoi(e));      // (out-of-range values are ignored)
     c->err.clear();
@@ -903,6 +932,9 @@ int hg_set_option(hg_ctx* c, const char* key, int value) {
     else if (k == "adapter_fuse") c->opt_adapter_fuse = value != 0;
     else if (k == "adapter_fold") c->opt_adapter_fold = value != 0;
     else if (k == "stream_hilo") c->opt_stream_hilo = value != 0;
+    else if (k == "qkv_attn") c->opt_qkv_attn = value != 0;
+    else if (k == "qkv_attn_min_seq") { if (value >= 1) c->opt_qkv_attn_min_seq = value; }
+    else if (k == "qkv_attn_gsz") { if (value >= 0 && value <= 6) c->opt_qkv_attn_gsz = value; }
     else return fail(c, HG_ERR_INVALID, "unknown option '%s'", key);
     return HG_OK;
 }
@@ -916,6 +948,9 @@ int hg_get_option(hg_ctx* c, const char* key, int* value) {
     else if (k == "adapter_fuse") *value = c->opt_adapter_fuse;
     else if (k == "adapter_fold") *value = c->opt_adapter_fold;
     else if (k == "stream_hilo") *value = c->opt_stream_hilo;
+    else if (k == "qkv_attn") *value = c->opt_qkv_attn;
+    else if (k == "qkv_attn_min_seq") *value = c->opt_qkv_attn_min_seq;
+    else if (k == "qkv_attn_gsz") *value = c->opt_qkv_attn_gsz;
     else return fail(c, HG_ERR_INVALID, "unknown option '%s'", key);
     return HG_OK;
 }
@@ -1162,6 +1197,75 @@ int hg_test_attention(hg_ctx* c, const float* qkv, const float* q0, const int32_
         HG_HIP(attention(c, (const half_t*)c->qkv.p, (half_t*)c->att.p, n_seq, L, heads, causal != 0, s));
         HG_HIP(launch_f16_to_f32((const half_t*)c->att.p, out, M * D, s));
     }
+    return HG_OK;
+}
+
+int hg_test_qkv_attn(hg_ctx* c, const float* a, const float* w, const float* bias, const float* cs, const float* mr, int n_seq,
+                     int L, int heads, int fused, float* out, void* stream) {
+    if (!c || !a || !w || !cs || !mr || !out || n_seq <= 0 || heads < 1) return HG_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    HG_ON_DEVICE(c);
+    const int D = heads * 64, M = n_seq * L;
+    const size_t Mp = rup(M, 256);
+    if (fused && !qkv_attn_ok(n_seq, L, D, heads, D)) return fail(c, HG_ERR_INVALID, "hg_test_qkv_attn: shape not eligible for the fused kernel");
+    int rc = ensure(c, c->h, Mp * D * 2);
+    if (!rc) rc = ensure(c, c->fc, (size_t)3 * D * D * 2 * 2 + (size_t)(heads / 2 + 1) * 768 * 4);
+    if (!rc) rc = ensure(c, c->qkv, Mp * 3 * D * 2);
+    if (!rc) rc = ensure(c, c->att, Mp * D * 2);
+    if (!rc) rc = ensure(c, c->mr, Mp * 2 * 4);
+    if (rc) return rc;
+    half_t* w16 = (half_t*)c->fc.p;
+    half_t* wp = w16 + (size_t)3 * D * D;
+    float* bcs = (float*)(wp + (size_t)3 * D * D);
+    HG_HIP(launch_f32_to_f16(a, (half_t*)c->h.p, (size_t)M * D, s));
+    HG_HIP(launch_f32_to_f16(w, w16, (size_t)3 * D * D, s));
+    HG_HIP(hipMemsetAsync(c->mr.p, 0, Mp * 2 * 4, s));
+    HG_HIP(hipMemcpyAsync(c->mr.p, mr, (size_t)M * 2 * 4, hipMemcpyDeviceToDevice, s));
+    HG_HIP(hipMemsetAsync(c->att.p, 0, Mp * D * 2, s));
+    if (fused) {
+        HG_HIP(launch_pack_qkv(w16, bias, cs, wp, bcs, D, heads, s));
+        QkvAttnArgs qa{};
+        qa.x16 = (const half_t*)c->h.p; qa.lda = D; qa.wp = wp; qa.bcs = bcs; qa.mr = (const float*)c->mr.p;
+        qa.out = (half_t*)c->att.p; qa.ldo = D; qa.n_seq = n_seq; qa.L = L; qa.D = D; qa.heads = heads;
+        qa.gsz = c->opt_qkv_attn_gsz; qa.a_bytes = (unsigned)(Mp * (size_t)D * 2);
+#ifdef HG_STAMPS
+        if (!(rc = ensure(c, c->cq, 256 * 8 * 16 * 8))) qa.dbg = (unsigned long long*)c->cq.p;      // read back by tools/qkv_attn_stamps.py
+        else return rc;
+        HG_HIP(hipMemsetAsync(c->cq.p, 0, 256 * 8 * 16 * 8, s));
+#endif
+        ProfScope ps(c, s, HG_PROF_QKV_ATTN, n_seq, L, heads);
+        hipError_t e = launch_qkv_attn(qa, s);
+        ps.finish();
+        if (e != hipSuccess) return fail(c, HG_ERR_HIP, "test qkv_attn launch failed: %s", hipGetErrorString(e));
+#ifdef HG_STAMPS
+        {      // diagnostic build: median over workgroups of the per-wave s_memtime totals of every phase (hg_qkv_attn.hip QA_ST)
+            HG_HIP(hipStreamSynchronize(s));
+            std::vector<unsigned long long> hd((size_t)256 * 8 * 16);
+            HG_HIP(hipMemcpy(hd.data(), c->cq.p, hd.size() * 8, hipMemcpyDeviceToHost));
+            static const char* nm[9] = {"K loop", "drain+barrier", "LN fold + head a -> LDS", "attention a", "barrier", "head b -> LDS",
+                                        "attention b", "barrier", "whole kernel"};
+            for (int wv : {0, 3, 4, 6, 7}) {
+                fprintf(stderr, "[stamps] wave %d:", wv);
+                for (int k = 0; k < 9; ++k) {
+                    std::vector<unsigned long long> v;
+                    for (int b = 0; b < 256; ++b) if (hd[((size_t)b * 8 + wv) * 16 + 8]) v.push_back(hd[((size_t)b * 8 + wv) * 16 + k]);
+                    if (v.empty()) continue;
+                    std::sort(v.begin(), v.end());
+                    fprintf(stderr, " %s %llu |", nm[k], v[v.size() / 2]);
+                }
+                fprintf(stderr, "\n");
+            }
+        }
+#endif
+    } else {
+        GemmArgs g{};
+        g.A = (const half_t*)c->h.p; g.lda = D; g.W = w16; g.bias = bias; g.cs = cs; g.mr = (const float*)c->mr.p;
+        g.out = c->qkv.p; g.ldc = 3 * D; g.M = M; g.N = 3 * D; g.K = D;
+        if (!gemm_ln_ok(EPI_LN_BIAS_F16, g)) return fail(c, HG_ERR_INVALID, "hg_test_qkv_attn: shape not eligible for the folded GEMM");
+        HG_HIP(gemm(c, EPI_LN_BIAS_F16, g, s));
+        HG_HIP(attention(c, (const half_t*)c->qkv.p, (half_t*)c->att.p, n_seq, L, heads, false, s));
+    }
+    HG_HIP(launch_f16_to_f32((const half_t*)c->att.p, out, (size_t)M * D, s));
     return HG_OK;
 }
 

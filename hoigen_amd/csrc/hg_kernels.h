@@ -95,6 +95,29 @@ hipError_t launch_attention(const half_t* qkv, half_t* out, int n_seq, int L, in
 hipError_t launch_attention_row0(const half_t* qkv, const half_t* q0, const int32_t* sel, half_t* out, int n_seq, int L,
                                  int heads, bool causal, hipStream_t s);
 
+// ---- fused in_proj + attention (hg_qkv_attn.hip): out = SDPA(LN-folded in_proj(x16)) with q, k, v kept in LDS ----------------
+// x16 [n_seq * L, lda]: centred fp16 copy of the stream; wp / bcs: the LayerNorm-folded in_proj weight, bias' and column sums
+// packed by launch_pack_qkv; mr [n_seq * L][2] = (row mean minus the copy's centre, rstd); out fp16 [n_seq * L, ldo].
+struct QkvAttnArgs {
+    const half_t* x16 = nullptr;
+    int lda = 0;
+    const half_t* wp = nullptr;
+    const float* bcs = nullptr;
+    const float* mr = nullptr;
+    half_t* out = nullptr;
+    int ldo = 0;                 // 0 = D
+    int n_seq = 0, L = 0, D = 0, heads = 0;
+    unsigned a_bytes = 0;        // bytes readable behind x16 (0: rows padded to a multiple of 256)
+    int gsz = 0;                 // head pairs per XCD group (0 = all: the pairs of a sequence side by side)
+    unsigned long long* dbg = nullptr;   // diagnostics: s_memtime totals per wave (HG_STAMPS build), normally null
+};
+// 192 < L <= 208, D = 64 * heads, heads even, D / 64 a multiple of 3 (ViT-B/16: L = 197, D = 768)
+bool qkv_attn_ok(int n_seq, int L, int D, int heads, int lda);
+// W [3D, D] fp16 (LayerNorm-folded), bias / cs [3D] -> Wp [3D * D] fp16 in fragment order, bcs [heads / 2][768] fp32
+hipError_t launch_pack_qkv(const half_t* W, const float* bias, const float* cs, half_t* Wp, float* bcs, int D, int heads,
+                           hipStream_t s);
+hipError_t launch_qkv_attn(const QkvAttnArgs& a, hipStream_t s);
+
 // ---- elementwise / row kernels ---------------------------------------------------------------
 // LayerNorm over rows of fp32 x (eps 1e-5, biased variance; clipnet/model.py:153-159).
 // Input row for output row r:  gather ? r*rows_per_seq + gather[r] : r*in_row_stride_rows.

@@ -258,6 +258,7 @@ int hg_workspace_bytes(hg_ctx*, uint64_t* bytes);
 #define HG_PROF_OFF (-1)
 #define HG_PROF_ALL (-2)
 #define HG_PROF_ATTENTION 100 /* M = sequences, N = tokens per sequence, K = heads */
+#define HG_PROF_QKV_ATTN 101  /* fused in_proj + attention: M = sequences, N = tokens per sequence, K = heads */
 typedef struct {
     int32_t kind; /* GEMM epilogue class or HG_PROF_ATTENTION */
     int32_t M, N, K;
@@ -292,6 +293,14 @@ int hg_test_gemm_hilo(hg_ctx*, const float* a, const float* w, const float* bias
  * row 0 when sel is NULL - the row index only matters for the causal mask), out [n_seq, heads*64]. */
 int hg_test_attention(hg_ctx*, const float* qkv, const float* q0, const int32_t* sel, int n_seq, int L, int heads,
                       int causal, float* out, void* stream);
+
+/* Test hook for the fused in_proj + attention kernel (hoigen_amd/csrc/hg_qkv_attn.hip; the reference ops it replaces:
+ * clipnet/model.py:171,181-183).  a [n_seq*L, D] fp32 (rounded to fp16 inside: the centred copy of the stream), w [3D, D] the
+ * LayerNorm-folded in_proj weight, bias / cs [3D], mr [n_seq*L, 2] = (mean - centre, rstd), D = 64 * heads; out [n_seq*L, D]
+ * fp32 = the attention output.  fused != 0: the one kernel (192 < L <= 208, heads even, D / 64 a multiple of 3);
+ * fused == 0: the folded GEMM followed by hg_test_attention's kernel - the two must agree bit for bit. */
+int hg_test_qkv_attn(hg_ctx*, const float* a, const float* w, const float* bias, const float* cs, const float* mr, int n_seq,
+                     int L, int heads, int fused, float* out, void* stream);
 
 #ifdef __cplusplus
 }

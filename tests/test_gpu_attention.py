@@ -70,3 +70,57 @@ def test_one_row_variant_is_the_full_kernels_row(ctx, n_seq, L, heads, causal):
         q0 = qkv.view(n_seq, L, 3 * D)[torch.arange(n_seq, device="cuda"), idx, :D].contiguous()
         rows = run_rows(ctx, qkv, q0, sel, n_seq, L, heads, causal)
         assert torch.equal(rows, full[torch.arange(n_seq, device="cuda"), idx]), "same instruction sequence, same bits"
+
+
+# ---- in_proj + attention as ONE kernel (hg_qkv_attn.hip): q, k, v never leave the chip -------------------------------------
+def _qkv_attn_operands(n_seq, L, heads, seed):
+    D = heads * 64
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    a = torch.randn(n_seq * L, D, device="cuda", generator=g)                 # centred fp16 copy of the stream
+    w = torch.randn(3 * D, D, device="cuda", generator=g) * D ** -0.5         # LayerNorm-folded in_proj weight
+    bias = torch.randn(3 * D, device="cuda", generator=g) * 0.3
+    cs = w.half().float().sum(1)
+    mr = torch.stack([torch.randn(n_seq * L, device="cuda", generator=g) * 0.05,
+                      torch.rand(n_seq * L, device="cuda", generator=g) + 0.5], 1).contiguous()
+    return a, w, bias, cs, mr
+
+
+def run_qkv_attn(ctx, ops, n_seq, L, heads, fused):
+    a, w, bias, cs, mr = ops
+    out = torch.empty(n_seq * L, heads * 64, device="cuda")
+    rc = _lib.lib().hg_test_qkv_attn(ctx, a.data_ptr(), w.data_ptr(), bias.data_ptr(), cs.data_ptr(), mr.data_ptr(), n_seq, L,
+                                     heads, int(fused), out.data_ptr(), None)
+    assert rc == 0, _lib.lib().hg_last_error(ctx)
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("n_seq,L,heads", [(3, 197, 12), (8, 197, 12), (41, 197, 12), (256, 197, 12), (300, 197, 12),
+                                           (5, 193, 12), (4, 208, 12), (7, 200, 6), (19, 197, 6)])
+def test_fused_qkv_attention_equals_gemm_then_attention(ctx, n_seq, L, heads):
+    """The fused kernel against the two kernels it replaces (LayerNorm-folded in_proj GEMM, attention_kernel) on the same
+    operands: bit for bit, over ragged item counts (fewer items than CUs, not a multiple of the grid, several rounds per CU),
+    the shortest / longest sequence a row tile holds, and D = 384 (six K-tiles: every K-tile kind back to back); repeated
+    launches must agree (a race in the counted waits would show as a flaky mismatch); and against fp32 PyTorch."""
+    ops = _qkv_attn_operands(n_seq, L, heads, 1000 * L + 10 * n_seq + heads)
+    got = run_qkv_attn(ctx, ops, n_seq, L, heads, True)
+    if heads * 192 % 256 == 0:      # (the folded ring GEMM wants N = 3 D to be a multiple of 256: D = 384 only has the fp32 reference)
+        want = run_qkv_attn(ctx, ops, n_seq, L, heads, False)
+        assert torch.equal(got, want), f"max abs diff {(got - want).abs().max().item():.3e}"
+    for _ in range(3):
+        assert torch.equal(got, run_qkv_attn(ctx, ops, n_seq, L, heads, True))
+    a, w, bias, cs, mr = ops
+    D = heads * 64
+    qkv = ((a.half().float() @ w.half().float().t() - mr[:, :1] * cs[None]) * mr[:, 1:] + bias[None])
+    ref = ref_attention(qkv, n_seq, L, heads, False)
+    assert (got - ref).abs().max().item() <= 3e-3 * ref.abs().max().item()
+
+
+def test_fused_qkv_attention_under_xcd_group_sizes(ctx):
+    """The order in which an XCD walks its (sequence, head pair) items (option qkv_attn_gsz) never changes a result."""
+    n_seq, L, heads = 96, 197, 12
+    ops = _qkv_attn_operands(n_seq, L, heads, 77)
+    want = run_qkv_attn(ctx, ops, n_seq, L, heads, False)
+    for gsz in (1, 2, 3, 6, 0):
+        assert _lib.lib().hg_set_option(ctx, b"qkv_attn_gsz", gsz) == 0
+        assert torch.equal(run_qkv_attn(ctx, ops, n_seq, L, heads, True), want), gsz

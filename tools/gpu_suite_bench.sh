@@ -1,0 +1,11 @@
+#!/bin/bash
+# full GPU test suite, then the headline step with and without the fused in_proj + attention kernel (same box, alternating)
+R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out; cd $R
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/suite.log 2>&1; tail -4 gpurun_out/suite.log
+for v in ${ORDER:-1 0 1 0}; do HG_QKV_ATTN=$v timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extra-configs --no-class-rows > gpurun_out/qa_bench_$v.log 2>&1; python - $v <<'PY'
+import json,sys
+l=[x for x in open(f"gpurun_out/qa_bench_{sys.argv[1]}.log") if x.startswith('{')]
+if not l: print('bench FAILED', open(f"gpurun_out/qa_bench_{sys.argv[1]}.log").read()[-1500:]); sys.exit()
+d=json.loads(l[-1]); print(f"HG_QKV_ATTN={sys.argv[1]}: {d['ms_per_step']} ms/step e2e {d['roofline']['e2e_frac']} | " + ' | '.join(f"{k['name'][:14]} {k['avg_ms']*1e3:.0f}" for k in d['kernels'][:8]))
+PY
+done
