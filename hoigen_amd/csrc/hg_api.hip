@@ -320,6 +320,7 @@ int load_blocks(hg_ctx* c, std::vector<void*>& owned, const hg_block_weights* sr
             if (rc) return rc < 0 ? rc : HG_ERR_OOM;
             HG_HIP(launch_pack_qkv(b.wf_qkv, b.bf_qkv, b.cs_qkv, b.wp_qkv, b.bcs_qkv, D, D / 64, 0));
         }
+
     }
     return HG_OK;
 }
@@ -1122,8 +1123,10 @@ int hg_test_gemm_ln(hg_ctx* c, const float* a, const float* w, const float* bias
         g.pos = scale;
     }
     hipError_t e;
-    if (kernel == 2) e = gemm_ln_ok(epi, g) ? launch_gemm_ring(epi, g, s) : hipErrorInvalidValue;
-    else if (kernel == 3) e = gemm_duo_ok(epi, g) ? launch_gemm_duo(epi, g, s) : hipErrorInvalidValue;
+    if (kernel == 2) {
+        ProfScope ps(c, s, epi, M, N, K);
+        e = gemm_ln_ok(epi, g) ? launch_gemm_ring(epi, g, s) : hipErrorInvalidValue;
+    } else if (kernel == 3) e = gemm_duo_ok(epi, g) ? launch_gemm_duo(epi, g, s) : hipErrorInvalidValue;
     else e = launch_gemm(epi, g, s);
     if (e != hipSuccess) return fail(c, HG_ERR_HIP, "test gemm (ln) launch failed: %s", hipGetErrorString(e));
     if (lnc) {

@@ -17,8 +17,8 @@
 //   W: packed once at load time into MFMA-fragment order (pack_qkv_kernel), streamed from L2 into WAVE-PRIVATE rings of one
 //     K-tile (2 x 3 fragments of 1 KiB, read with ds_read_b128 at lane * 16: no swizzle, no sharing, no barrier); a slot is
 //     refilled with the next K-tile's fragment as soon as its 13 MFMAs are issued.
-//   One s_barrier per K-tile, counted vmcnt throughout; K-tiles are instantiated by position (first / middle / second to
-//   last / last) because the VMEM sequence differs there (below).  Bytes through the CU's load path per K-tile: 26 KiB of A +
+//   One s_barrier per K-tile (five fragment reads before its end, so that no wave drains at the boundary), counted vmcnt
+//   throughout; K-tiles are instantiated by position (first / middle / last) because the VMEM sequence differs there (below).  Bytes through the CU's load path per K-tile: 26 KiB of A +
 //   48 KiB of W for 2 x 13 x 24 MFMAs = 7.4 KB per MFLOP (the 256 x 256 ring: 7.6, the 128 x 256 ring2: 11.4).
 // Epilogue: rstd * (acc - (mean - c) * cs) + b' as in the EPI_LN_BIAS_F16 epilogue of hg_gemm_ring.hip (same expression,
 //   same rounding to fp16), written to LDS as Q, K, V rows of 128 B in the layout attention_kernel stages them in.
@@ -36,20 +36,17 @@
 #include <type_traits>
 
 #include "hg_attn_dev.h"
-#include "hg_gemm_dev.h"
+#include "hg_seq_dev.h"
 
 namespace hg {
 
 namespace {
-constexpr int QA_RB = 13;                          // 16-row blocks of a sequence tile
-constexpr int QA_NCB = 3;                          // 16-column blocks per wave
-constexpr int QA_NA = 3;                           // A pieces (1 KiB = 8 rows) per wave and K-tile; waves 0 and 1 issue one more
-constexpr int QA_WSLOT = 2 * QA_NCB * 1024;        // one wave's W ring: a K-tile of fragments
-constexpr int QA_ASTG = QA_RB * 2048;              // one A stage = one Q / K / V matrix: 208 rows x 128 B
-constexpr int QA_A0 = 8 * QA_WSLOT;
-constexpr int QA_ATT = QA_A0 + QA_ASTG;
-constexpr int QA_ATT_BYTES = 80 * 1024;            // 3 x QA_ASTG + slack (tile 6 of Q / K reads 16 rows into the next matrix)
-constexpr int QA_BCS = QA_ATT + QA_ATT_BYTES;      // bias'[384] | cs[384] in tile column order
+constexpr int QA_RB = SQ_RB;                       // 16-row blocks of a sequence tile
+constexpr int QA_NCB = SQ_NCB;                     // 16-column blocks per wave
+constexpr int QA_ASTG = SQ_ASTG;                   // one A stage = one Q / K / V matrix: 208 rows x 128 B
+constexpr int QA_ATT = SQ_S12;                     // stages 1 and 2 of the K loop = the attention operands
+constexpr int QA_ATT_BYTES = SQ_S12_BYTES;         // 3 x QA_ASTG + slack (tile 6 of Q / K reads 16 rows into the next matrix)
+constexpr int QA_BCS = SQ_END;                     // bias'[384] | cs[384] in tile column order
 constexpr int QA_MR = QA_BCS + 2 * 384 * 4;
 constexpr int QA_LDS = QA_MR + QA_RB * 16 * 8;
 static_assert(QA_LDS <= 160 * 1024, "LDS budget");
@@ -65,11 +62,10 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnArgs p, c
 #else
     constexpr int xmode = 0;
 #endif
-    constexpr int RB = QA_RB, NCB = QA_NCB, NA = QA_NA;
+    constexpr int RB = QA_RB, NCB = QA_NCB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int q = lane >> 4, r16 = lane & 15;
     const int nk = p.D >> 6;                       // K-tiles per item (a multiple of 3: stage of K-tile kt = kt % 3)
     const int HP = p.heads >> 1;
 
@@ -95,36 +91,12 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnArgs p, c
         hp = grp * gsz + (rem - s * gsz);
     };
 
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.x16, 0, p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsW =
-        __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (unsigned)((size_t)3 * p.D * p.D * 2), 0x00020000);
-
-    // A pieces of this wave: piece pc = wave + 8 i covers tile rows 8 pc .. 8 pc + 7; lane -> (row = l >> 3, chunk' = l & 7);
-    // 64 rows further down the swizzle repeats, so piece i is piece 0 plus a scalar offset
-    const int voffA = ((wave * 8 + (lane >> 3)) * p.lda + (((lane & 7) ^ ((lane >> 4) & 3) ^ ((wave & 1) << 2)) << 3)) * 2;
-    auto stage_base = [&](int st) { return st == 0 ? QA_A0 : QA_ATT + (st - 1) * QA_ASTG; };
-    // all pieces of one K-tile of a sequence's rows (26 pieces: waves 0 and 1 issue a fourth - an operation more only makes
-    // the counted waits below stricter, never looser)
-    auto issue_A = [&](int seq, int kt, int sbase) {
-        if (xmode & 8) return;
-        const int soff = (seq * p.L * p.lda + kt * 64) * 2;
-#pragma unroll
-        for (int i = 0; i < NA; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (HG_LDS void*)(smem + sbase + (wave + 8 * i) * 1024), 16, voffA,
-                                                     soff + i * 64 * p.lda * 2, 0, 0);
-        if (wave < 2)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (HG_LDS void*)(smem + sbase + (wave + 24) * 1024), 16, voffA,
-                                                     soff + 3 * 64 * p.lda * 2, 0, 0);
-    };
-    char* wring = smem + wave * QA_WSLOT;
-    // fragment slot (ks, c) of K-tile kt of head pair hp: Wp[hp][2 kt + ks][wave][c][lane][8]
-    auto issue_W = [&](int hp, int kt, const int slot) {
-        if (xmode & 8) return;
-        const int ks = slot / NCB, c = slot % NCB;
-        const int soff = ((((hp * 2 * nk + kt * 2 + ks) * 8 + wave) * NCB) + c) * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (HG_LDS void*)(wring + slot * 1024), 16, lane * 16, soff, 0, 0);
-    };
-    auto read_W = [&](int slot) { return *reinterpret_cast<const half8*>(wring + slot * 1024 + lane * 16); };
+#define SQ_A_PTR p.x16
+#define SQ_A_BYTES p.a_bytes
+#define SQ_LDA p.lda
+#define SQ_W_PTR p.wp
+#define SQ_W_BYTES (unsigned)((size_t)3 * p.D * p.D * 2)
+#include "hg_seq_kloop.inc"
     // bias' | cs of the pair (3 KiB: waves 0-2) and (mean - c, rstd) of the sequence's rows (208 x 8 B: waves 3 and 4)
     auto issue_extras = [&](int seq, int hp) {
         // (descriptors built here, once per item: they would otherwise sit in 8 SGPRs through the K loop)
@@ -143,20 +115,10 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnArgs p, c
         }
     };
 
-    // lane-constant LDS read offsets of the activation fragments
-    const int a_lane = r16 * 128;
-    int coff[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) coff[ks] = ((ks * 4 + q) ^ ((lane >> 1) & 7)) << 4;
-
     // ---- prologue: K-tile 0 of the first item
     int e = idx, seq, hp;
     decode(e, seq, hp);
-    issue_A(seq, 0, QA_A0);
-#pragma unroll
-    for (int slot = 0; slot < 2 * NCB; ++slot) issue_W(hp, 0, slot);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    barrier_raw();
+    seq_prologue(seq * p.L, hp);
 
 #ifdef HG_STAMPS
     unsigned long long tst[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime(), t_all0 = t_prev;
@@ -170,106 +132,17 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnArgs p, c
         int seq_n = seq, hp_n = hp;          // no next item: the run-ahead loads fetch this item's first K-tile again (never read)
         if (has_next) decode(e_n, seq_n, hp_n);
 
-        // the attention phases of the previous item have released the 80 KiB: the epilogue's tables and stage 1 (stage 2 follows
-        // from inside the first K-tile)
+        // the attention phases of the previous item have released the 80 KiB: the epilogue's tables, then the K loop (stages 1, 2)
         issue_extras(seq, hp);
-        issue_A(seq, 1, stage_base(1));
-
         f32x4 acc[RB][NCB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
             for (int c = 0; c < NCB; ++c) acc[rb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-        // One K-tile = two k-steps of 32.  A k-step: the wave's 3 W fragments sit in registers (wc), the 13 activation
-        // fragments stream through a ring of six registers, five reads ahead of the MFMAs: 3 MFMAs per LDS read, 48 fragment
-        // registers in all beside the 156 accumulators.  The next k-step's W fragments (wn) are read near the end of the step,
-        // the slots are refilled by DMA as soon as their fragments are in registers.
-        //   VMEM operations of K-tile kt in issue order:   R_0 R_1 R_2  A A A  |  R_3 R_4 R_5
-        //     R_j: refill of W slot j with K-tile kt+1's fragment; A: the pieces of stage kt+2 (into the stage K-tile kt-1 left
-        //     at the barrier that ended it).
-        //   Counted waits (vmcnt is in issue order):
-        //     before reading slots 3-5 (end of step 0):  R_3-5 of K-tile kt-1 landed; issued since: R_0-2, A A A          -> 6
-        //     before reading slots 0-2 (end of step 1):  R_0-2 of this K-tile landed; issued since: A A A, R_3-5          -> 6
-        //       (that wait also covers stage kt+1, issued a K-tile earlier: no wait of its own)
-        //   then lgkmcnt(0) + s_barrier: publishes stage kt+1, frees stage kt.
-        // KIND 0: first K-tile of an item (its operands landed before the previous item's epilogue, its W fragments are read
-        // here), 1: middle, 2: last (stages 1 and 2 of the next item overlay the attention operands: no A group; the R_j fetch the
-        // next item's first K-tile; nothing is read ahead).
-        constexpr int AR = 6;                      // activation-fragment ring: AR - 1 reads (of 3 MFMAs each) ahead
-        half8 wc[NCB], wn[NCB], afr[AR];
-        auto read_af = [&](int sbase, int ks, int rb, int slot) {
-            afr[slot] = *reinterpret_cast<const half8*>(smem + sbase + a_lane + rb * 2048 + coff[ks]);
-        };
-        auto ktile = [&](const int kt, const int st_cur, auto KIND_T) {
-            constexpr int KIND = decltype(KIND_T)::value;
-            constexpr bool FIRST = KIND == 0, LAST = KIND == 2;
-            const int sb_cur = stage_base(st_cur);
-#pragma unroll
-            for (int i = 0; i < AR - 1; ++i) read_af(sb_cur, 0, i, i);
-            if constexpr (FIRST) {
-#pragma unroll
-                for (int c = 0; c < NCB; ++c) wc[c] = read_W(c);
-            }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                if (!(xmode & 2)) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int rb = 0; rb < RB; ++rb) {
-                    const int pos = ks * RB + rb;
-                    if (pos + AR - 1 < 2 * RB) read_af(sb_cur, (pos + AR - 1) / RB, (pos + AR - 1) % RB, (pos + AR - 1) % AR);
-                    if (rb == RB - 3 && !(LAST && ks == 1)) {
-                        // W fragments of the next k-step (the other half of the ring, or the next K-tile's first half)
-                        if constexpr (FIRST) { if (ks == 1) wait_vm<2 * NCB>(); }
-                        else if constexpr (LAST) wait_vm<NCB>();
-                        else wait_vm<2 * NCB>();
-#pragma unroll
-                        for (int c = 0; c < NCB; ++c) wn[c] = read_W((1 - ks) * NCB + c);
-                    }
-                    if (xmode & 2) {
-#pragma unroll
-                        for (int c = 0; c < NCB; ++c) asm volatile("" ::"v"(afr[pos % AR]), "v"(wc[c]));
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < NCB; ++c)
-                            acc[rb][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[c], afr[pos % AR], acc[rb][c], 0, 0, 0);
-                    }
-                    if (rb == 0) {
-                        // the step's W fragments are in registers (the MFMAs above waited for them): refill their slots
-                        asm volatile("" ::"v"(wc[0]), "v"(wc[1]), "v"(wc[2]) : "memory");
-#pragma unroll
-                        for (int c = 0; c < NCB; ++c) {
-                            if constexpr (LAST) issue_W(hp_n, 0, ks * NCB + c);
-                            else issue_W(hp, kt + 1, ks * NCB + c);
-                        }
-                        if (ks == 0 && !LAST) {
-                            const int st_free = st_cur == 0 ? 2 : st_cur - 1;      // stage of K-tile kt-1 = stage of K-tile kt+2
-                            if (kt + 2 < nk) issue_A(seq, kt + 2, stage_base(st_free));
-                            else issue_A(seq_n, 0, stage_base(st_free));           // kt = nk - 2, stage 0: the next item's first K-tile
-                        }
-                        asm volatile("" ::: "memory");
-                    }
-                }
-                if (!(xmode & 2)) __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-                for (int c = 0; c < NCB; ++c) wc[c] = wn[c];
-            }
-            if constexpr (!LAST) {
-                __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's reads of stage kt are done
-                barrier_raw();
-            }
-        };
-        ktile(0, 0, std::integral_constant<int, 0>{});
         {
-            int st = 1;
-            for (int kt = 1; kt < nk - 1; ++kt) {
-                ktile(kt, st, std::integral_constant<int, 1>{});
-                st = st == 2 ? 0 : st + 1;
-            }
-            ktile(nk - 1, st, std::integral_constant<int, 2>{});
+            const int sq_row0 = seq * p.L, sq_pn = hp, sq_row0_n = seq_n * p.L, sq_pn_n = hp_n;
+#include "hg_seq_kloop_run.inc"
         }
-        // the next item's first K-tile is in flight: land it before the attention phases' stores enter vmcnt, and publish it
-        // together with the epilogue's tables; every wave is done with the A stages
         QA_ST(0);      // K loop
         wait_vm<0>();
         __builtin_amdgcn_s_waitcnt(0xC07F);
