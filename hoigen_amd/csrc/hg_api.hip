@@ -144,6 +144,7 @@ struct hg_ctx {
     // sticky device->host flag (host-mapped): set by clamp_eot when a caller-supplied text truncation was shorter than
     // max(EOT)+1 (a stale host memo); reported as HG_ERR_INVALID by the next text call
     int32_t* eot_flag = nullptr;
+    int32_t* eot_flag_dev = nullptr;   // the same condition for the call in flight, in device memory (zeroed per call): poison_if_flag polls it
     // live per-kernel timing for bench.py (hg_profile_begin/end): hipEvent pairs around the launches of one kernel
     // kind (or of every GEMM and attention launch), on the stream the kernel is launched on
     int prof_kind = HG_PROF_OFF;
@@ -910,6 +911,8 @@ hg_ctx* hg_create(int device) {
         DevGuard g(c);
         if (hipHostMalloc((void**)&c->eot_flag, 64, hipHostMallocMapped) == hipSuccess && c->eot_flag) *c->eot_flag = 0;
         else c->eot_flag = nullptr;
+        if (hipMalloc((void**)&c->eot_flag_dev, 64) != hipSuccess) c->eot_flag_dev = nullptr;
+        else (void)hipMemset(c->eot_flag_dev, 0, 64);
     }
     struct { const char* env; const char* key; } init[] = {{"HG_CHUNK_ROWS", "chunk_rows"}, {"HG_LAST_BLOCK_ROW0", "last_block_row0"},
                                                            {"HG_LN_FUSE", "ln_fuse"}, {"HG_ADAPTER_FUSE", "adapter_fuse"},
@@ -972,6 +975,7 @@ void hg_destroy(hg_ctx* c) {
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     if (c->eot_flag) (void)hipHostFree(c->eot_flag);
+    if (c->eot_flag_dev) (void)hipFree(c->eot_flag_dev);
     delete c;
 }
 
@@ -1245,11 +1249,12 @@ int hg_test_qkv_attn(hg_ctx* c, const float* a, const float* w, const float* bia
             HG_HIP(hipStreamSynchronize(s));
             std::vector<unsigned long long> hd((size_t)256 * 8 * 16);
             HG_HIP(hipMemcpy(hd.data(), c->cq.p, hd.size() * 8, hipMemcpyDeviceToHost));
-            static const char* nm[9] = {"K loop", "drain+barrier", "LN fold + head a -> LDS", "attention a", "barrier", "head b -> LDS",
-                                        "attention b", "barrier", "whole kernel"};
+            static const char* nm[14] = {"K loop", "drain+barrier", "barrier behind head a", "attention a", "barrier", "head b -> LDS",
+                                         "attention b", "barrier", "whole kernel", "LN fold", "head a -> LDS", "K loop: wait A", "K loop: barrier",
+                                         "K loop: wait W"};
             for (int wv : {0, 3, 4, 6, 7}) {
                 fprintf(stderr, "[stamps] wave %d:", wv);
-                for (int k = 0; k < 9; ++k) {
+                for (int k = 0; k < 14; ++k) {
                     std::vector<unsigned long long> v;
                     for (int b = 0; b < 256; ++b) if (hd[((size_t)b * 8 + wv) * 16 + 8]) v.push_back(hd[((size_t)b * 8 + wv) * 16 + k]);
                     if (v.empty()) continue;
@@ -1720,6 +1725,7 @@ int hg_encode_text_ids(hg_ctx* c, const int32_t* ids, int T, int L, float* out, 
     HG_ON_DEVICE(c);
     if (int frc = text_check_flag(c)) return frc;
     const int Leff = (trunc > 0 && trunc < L) ? trunc : L;
+    if (Leff < L && c->eot_flag_dev) HG_HIP(hipMemsetAsync(c->eot_flag_dev, 0, 4, s));
     for (int t0 = 0; t0 < T; t0 += c->max_chunk_txt) {
         const int Tc = (T - t0 < c->max_chunk_txt) ? T - t0 : c->max_chunk_txt;
         int rc = ensure_tower_ws(c, Tc * Leff, t.D);
@@ -1729,12 +1735,12 @@ int hg_encode_text_ids(hg_ctx* c, const int32_t* ids, int T, int L, float* out, 
         int32_t* eot = (int32_t*)c->i32.p;
         // EOT position = argmax over the FULL row (clipnet/model.py:350); must lie inside Leff
         HG_HIP(launch_eot_argmax(ids + (size_t)t0 * L, Tc, L, eot, nullptr, s));
-        if (Leff < L) HG_HIP(launch_clamp_eot(eot, Tc, Leff, eot, c->eot_flag, s));
+        if (Leff < L) HG_HIP(launch_clamp_eot(eot, Tc, Leff, eot, c->eot_flag, s, c->eot_flag_dev));
         HG_HIP(launch_embed_tokens(ids + (size_t)t0 * L, L, t.tok, t.pos, (float*)c->x.p, Tc, Leff, t.D, t.vocab, s));
         rc = text_tail(c, Tc, Leff, eot, out + (size_t)t0 * t.E, s);
         if (rc) return rc;
     }
-    if (Leff < L) HG_HIP(launch_poison_if_flag(out, (size_t)T * t.E, c->eot_flag, s));
+    if (Leff < L) HG_HIP(launch_poison_if_flag(out, (size_t)T * t.E, c->eot_flag_dev, s));
     return HG_OK;
 }
 
@@ -1750,6 +1756,7 @@ int hg_encode_text_embeds(hg_ctx* c, const float* prompts, const int32_t* eot_id
     HG_ON_DEVICE(c);
     if (int frc = text_check_flag(c)) return frc;
     const int Leff = (trunc > 0 && trunc < L) ? trunc : L;
+    if (Leff < L && c->eot_flag_dev) HG_HIP(hipMemsetAsync(c->eot_flag_dev, 0, 4, s));
     for (int r0 = 0; r0 < R; r0 += c->max_chunk_txt) {
         const int Rc = (R - r0 < c->max_chunk_txt) ? R - r0 : c->max_chunk_txt;
         int rc = ensure_tower_ws(c, Rc * Leff, t.D);
@@ -1760,13 +1767,13 @@ int hg_encode_text_embeds(hg_ctx* c, const float* prompts, const int32_t* eot_id
         if (Leff < L) {
             rc = ensure(c, c->i32, (size_t)(Rc + 4) * 4);
             if (rc) return rc;
-            HG_HIP(launch_clamp_eot(eot, Rc, Leff, (int32_t*)c->i32.p, c->eot_flag, s));
+            HG_HIP(launch_clamp_eot(eot, Rc, Leff, (int32_t*)c->i32.p, c->eot_flag, s, c->eot_flag_dev));
             eot = (const int32_t*)c->i32.p;
         }
         rc = text_tail(c, Rc, Leff, eot, out + (size_t)r0 * t.E, s);
         if (rc) return rc;
     }
-    if (Leff < L) HG_HIP(launch_poison_if_flag(out, (size_t)R * t.E, c->eot_flag, s));
+    if (Leff < L) HG_HIP(launch_poison_if_flag(out, (size_t)R * t.E, c->eot_flag_dev, s));
     return HG_OK;
 }
 

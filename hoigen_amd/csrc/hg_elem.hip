@@ -228,24 +228,27 @@ hipError_t launch_eot_argmax(const int32_t* ids, int T, int L, int32_t* eot, int
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void clamp_eot_kernel(const int32_t* in, int n, int Leff, int32_t* out, int32_t* flag) {
+__global__ __launch_bounds__(256) void clamp_eot_kernel(const int32_t* in, int n, int Leff, int32_t* out, int32_t* flag,
+                                                        int32_t* flag_dev) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     int v = in[i];
     if (v >= Leff) {
         if (flag) *flag = 1;
+        if (flag_dev) *flag_dev = 1;
         v = Leff - 1;
     }
     out[i] = v < 0 ? 0 : v;
 }
-hipError_t launch_clamp_eot(const int32_t* in, int n, int Leff, int32_t* out, int32_t* flag, hipStream_t s) {
+hipError_t launch_clamp_eot(const int32_t* in, int n, int Leff, int32_t* out, int32_t* flag, hipStream_t s, int32_t* flag_dev) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(clamp_eot_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, n, Leff, out, flag);
+    hipLaunchKernelGGL(clamp_eot_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, n, Leff, out, flag, flag_dev);
     return hipGetLastError();
 }
 
 // A truncation length that did not cover every EOT row (flag set by clamp_eot_kernel earlier in the same call): the call's
 // whole output becomes NaN - the stale call itself is loud, not only the next one (it cannot be failed without a sync)
+// (flag: DEVICE memory - a quarter of a million lanes polling a host-mapped word over PCIe cost 0.7 ms per call)
 __global__ __launch_bounds__(256) void poison_if_flag_kernel(float* out, size_t n, const int32_t* flag) {
     if (*(const volatile int32_t*)flag == 0) return;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = __builtin_nanf("");

@@ -137,9 +137,10 @@ hipError_t launch_add_pos(const float* prompts, int Lfull, const float* pos, flo
 hipError_t launch_gather_rows(const int32_t* ids, const float* table, float* out, int n, int D, int vocab,
                               hipStream_t s);
 hipError_t launch_eot_argmax(const int32_t* ids, int T, int L, int32_t* eot, int32_t* max_eot, hipStream_t s);
-// out[i] = min(max(in[i], 0), Leff - 1); *flag = 1 (host-mapped, sticky) if any in[i] >= Leff.  in may equal out.
-hipError_t launch_clamp_eot(const int32_t* in, int n, int Leff, int32_t* out, int32_t* flag, hipStream_t s);
-// out[0..n) = NaN if *flag != 0 (flag: device-visible, set earlier on the same stream)
+// out[i] = min(max(in[i], 0), Leff - 1); *flag = 1 (host-mapped, sticky) and *flag_dev = 1 (device memory, per call) if any
+// in[i] >= Leff.  in may equal out.
+hipError_t launch_clamp_eot(const int32_t* in, int n, int Leff, int32_t* out, int32_t* flag, hipStream_t s, int32_t* flag_dev = nullptr);
+// out[0..n) = NaN if *flag != 0 (flag: DEVICE memory, set earlier on the same stream)
 hipError_t launch_poison_if_flag(float* out, size_t n, const int32_t* flag, hipStream_t s);
 hipError_t launch_f32_to_f16(const float* in, half_t* out, size_t n, hipStream_t s);
 hipError_t launch_f16_to_f32(const half_t* in, float* out, size_t n, hipStream_t s);

@@ -36,6 +36,10 @@
 #include <type_traits>
 
 #include "hg_attn_dev.h"
+#ifdef HG_STAMPS      // s_memtime brackets around the K loop's waits (hg_seq_kloop_run.inc): totals in tks[], reported as stamps 12-14
+#define SQ_STAMP_B() do { tk_b = __builtin_amdgcn_s_memtime(); } while (0)
+#define SQ_STAMP_E(k) do { tks[k] += __builtin_amdgcn_s_memtime() - tk_b; } while (0)
+#endif
 #include "hg_seq_dev.h"
 
 namespace hg {
@@ -121,7 +125,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnArgs p, c
     seq_prologue(seq * p.L, hp);
 
 #ifdef HG_STAMPS
-    unsigned long long tst[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime(), t_all0 = t_prev;
+    unsigned long long tks[3] = {0, 0, 0}, tk_b = 0;
+    unsigned long long tst[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime(), t_all0 = t_prev;
 #define QA_ST(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tst[k] += t_ - t_prev; t_prev = t_; } while (0)
 #else
 #define QA_ST(k) do {} while (0)
@@ -251,11 +256,11 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnArgs p, c
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks) kf[b][ks] = *reinterpret_cast<const half8*>(Ks + kt * TILEB + k_off[ks]);
                 };
-                auto scores = [&](int b) {      // = tile_scores()
+                const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                auto scores = [&](int b) {      // = tile_scores() (the first MFMA takes the zero accumulator as an inline constant)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) sc[b][r] = 0.f;
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) sc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[b][ks], qf[ks], sc[b], 0, 0, 0);
+                    for (int ks = 0; ks < 4; ++ks)
+                        sc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[b][ks], qf[ks], ks == 0 ? zero16 : sc[b], 0, 0, 0);
                 };
                 auto max3 = [](float a, float b, float c) {      // (fmaxf would canonicalise every input: twice the instructions)
                     float d;
@@ -283,11 +288,10 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnArgs p, c
                     for (int st = 0; st < 2; ++st) {
                         if (st == 1 && !two_steps) break;
 #pragma unroll
-                        for (int dt = 0; dt < 2; ++dt) {
-                            const unsigned va = v_addr[dt] + kt * TILEB + st * (16 * ROWB);
-                            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024"
+                        for (int dt = 0; dt < 2; ++dt) {      // (tile and step offset as immediates: < 64 KiB)
+                            asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
                                          : "=&v"(vr[st][dt][0]), "=&v"(vr[st][dt][1])
-                                         : "v"(va)
+                                         : "v"(v_addr[dt]), "n"(kt * TILEB + st * (16 * ROWB)), "n"(kt * TILEB + st * (16 * ROWB) + 1024)
                                          : "memory");
                         }
                     }
@@ -321,10 +325,6 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnArgs p, c
                     const float mc = m * cexp;
                     half8 pf[2];
                     float ex[16];
-                    if (more) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) sc[nxt][r] = 0.f;
-                    }
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
 #pragma unroll
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnArgs p, c
                             pf[r >> 3][r & 7] = (half_t)ex[r];
                         }
                         __builtin_amdgcn_sched_barrier(0);
-                        if (more) sc[nxt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[nxt][g4], qf[g4], sc[nxt], 0, 0, 0);
+                        if (more) sc[nxt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[nxt][g4], qf[g4], g4 == 0 ? zero16 : sc[nxt], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     // ---- O^T[d][q] += sum_key V[key][d] P[q][key]; the row sum (in tile_softmax_pv's order) rides between the MFMAs
@@ -391,10 +391,12 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnArgs p, c
                     }
                 }
             };
+            QA_ST(9);      // (LayerNorm fold arithmetic)
             if (wave < 4) write_head();
             __builtin_amdgcn_s_waitcnt(0xC07F);
+            QA_ST(10);     // (head a -> LDS)
             barrier_raw();
-            QA_ST(2);      // LayerNorm fold + head a -> LDS + barrier
+            QA_ST(2);      // barrier behind them
             attend(2 * hp);
             QA_ST(3);      // attention a
             __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -421,6 +423,11 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnArgs p, c
 #pragma unroll
         for (int k = 0; k < 8; ++k) d[k] = tst[k];
         d[8] = __builtin_amdgcn_s_memtime() - t_all0;
+        d[9] = tst[9];
+        d[10] = tst[10];
+        d[11] = tks[0];
+        d[12] = tks[1];
+        d[13] = tks[2];
     }
 #endif
 #endif

@@ -35,6 +35,16 @@ constexpr int SQ_END = SQ_S12 + SQ_S12_BYTES;      // first free byte behind the
 #define SQ_AR 6                                    // activation-fragment ring: SQ_AR - 1 reads ahead (3 or 6: 26 positions = 2 mod SQ_AR)
 #endif
 
+#ifndef SQ_PRIO
+#define SQ_PRIO 0                                  // s_setprio of the MFMA stream: 0 both waves of a SIMD raised, 1 none, 2 only the younger wave
+#endif
+
+// Diagnostic hooks of the loop (s_memtime brackets around its waits): defined by a kernel's HG_STAMPS build, otherwise nothing
+#ifndef SQ_STAMP_B
+#define SQ_STAMP_B() do {} while (0)
+#define SQ_STAMP_E(k) do {} while (0)
+#endif
+
 // The loop itself is hg_seq_kloop.inc: a block of lambdas expanded inside the kernel that uses it (a struct of helpers costs the
 // compiler its view of the one extern __shared__ array: it then waits vmcnt(0) in front of every ds_read while an LDS-DMA is in
 // flight, and the accumulators stop being updated in place).
