@@ -29,6 +29,7 @@ Extra objects on the line:
                    this box's host cores on a bounded sample (rank 0, N = 1).
 """
 import argparse
+import ctypes
 import json
 import os
 import socket
@@ -326,6 +327,9 @@ def config4(dev, with_cpu: bool):
 
 
 # ---- per-kernel accounting ---------------------------------------------------------------------------------------
+RLN_STREAM_BYTES = 10.0      # algorithmic stream bytes per element of a LayerNorm-emitting residual GEMM (set in run())
+
+
 def kernel_row(kind, M, N, K):
     """(name, algorithmic FLOPs, algorithmic HBM bytes) of one launch."""
     if kind == 100:                       # attention: M sequences of N tokens, K heads of 64
@@ -342,9 +346,11 @@ def kernel_row(kind, M, N, K):
     if kind in (1, 9):
         return f"c_fc + QuickGELU (N={N}, K={K})", fl, M * K * 2 + w + M * N * 2
     if kind in (3, 10):
-        extra = M * N * 2 if kind == 10 else 0       # fp16 copy for the next LayerNorm-folded GEMM
+        # fp32 stream: read + write 4 B each (+ the 2-byte centred copy for the next LayerNorm-folded GEMM); stream held as
+        # centre + hi + lo (option stream_hilo): hi IS the copy - 4 B in, 4 B out (RLN_STREAM_BYTES: mean over the step's launches)
+        stream = RLN_STREAM_BYTES if kind == 10 else 8.0
         nm = "out_proj" if K == N else "c_proj"
-        return f"{nm} + residual (N={N}, K={K})", fl, M * K * 2 + w + 2 * M * N * 4 + extra
+        return f"{nm} + residual (N={N}, K={K})", fl, M * K * 2 + w + M * N * stream
     if kind == 5:
         return f"patch embedding (K={K})", fl, M * K * 2 + w + M * N * 4
     return f"{KIND_NAMES.get(kind, kind)} (M={M}, N={N}, K={K})", fl, M * K * 2 + w + M * N * 4
@@ -441,6 +447,12 @@ def run(args):
     model.visual.set_option("last_block_row0", 0)       # headline: every row of every block (hg_set_option on this context)
     for _ in range(args.warmup):
         step()
+    global RLN_STREAM_BYTES
+    hilo = ctypes.c_int32(0)
+    _lib.lib().hg_get_option(model.visual._ctx.handle, b"stream_hilo", ctypes.byref(hilo))
+    if hilo.value and args.batch * 197 >= 512:
+        # 23 such launches per all-rows step: the first reads fp32 and writes hi + lo (8 B), the last reads hi + lo and writes fp32 + copy (10 B)
+        RLN_STREAM_BYTES = (22 * 8.0 + 10.0) / 23
     # two more untimed steps with every GEMM / attention launch bracketed by events: the per-kernel table, and which
     # kernel the live `roofline` measurement of the timed region follows
     PROF_STEPS = 2

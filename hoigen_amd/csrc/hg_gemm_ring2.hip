@@ -115,7 +115,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
         const int dunit = mode >> 8;                               // estimated cycles per K-tile, 0 = off
         const int max_tiles = (T8 + cpx - 1) / cpx;
         if (dunit > 0 && my_tiles < max_tiles) {
-            const unsigned h = ((unsigned)bid * 2654435761u) >> 24;   // 0..255
+#ifndef HG_R2_DELAY_HASH
+#define HG_R2_DELAY_HASH 1
+#endif
+            // what the pseudo-random fraction is drawn from: 1 (default) the workgroup's XCD - the slack workgroups of an XCD stay in
+            // step with each other, they share activation panels through its L2: 583 instead of 670 MB fetched per launch, step
+            // -0.8 % (profiles/r04_energy_ab5_stagger.txt); 0 the workgroup itself (rounds 1-3), 2 the row panel of its first tile (worse)
+            const unsigned hkey = HG_R2_DELAY_HASH == 1 ? (unsigned)(bid & 7) * 37u + 11u
+                                  : HG_R2_DELAY_HASH == 2 ? (unsigned)(slot / (gsz > 0 ? gsz : 1)) : (unsigned)bid;
+            const unsigned h = (hkey * 2654435761u) >> 24;   // 0..255
             const long long d = ((long long)(max_tiles - my_tiles) * nk * dunit * h) >> 8;
             const unsigned long long t0 = __builtin_amdgcn_s_memtime();
             while ((long long)(__builtin_amdgcn_s_memtime() - t0) < d) __builtin_amdgcn_s_sleep(32);

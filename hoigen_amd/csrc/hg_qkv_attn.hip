@@ -268,8 +268,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnArgs p, c
                     return d;
                 };
                 // An in-order wave issues nothing behind an MFMA that waits for the matrix pipe, so the four S^T MFMAs of the NEXT
-                // tile are spread over this tile's exponentials (four elements between two MFMAs) and the four P V MFMAs over
-                // the serial row-sum chain: MFMA and VALU of ONE wave overlap (sched_barrier pins the order).
+                // tile are spread over this tile's exponentials (four elements between two MFMAs): MFMA and VALU of ONE wave overlap
+                // (sched_barrier pins the order).
                 load_k(0, 0);
                 load_k(1, 1);
                 scores(0);
@@ -324,25 +324,25 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnArgs p, c
                     }
                     const float mc = m * cexp;
                     half8 pf[2];
-                    float ex[16];
+                    float ps = 0.f;      // (summed in tile_softmax_pv's order: r = 0 .. 15)
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
 #pragma unroll
                         for (int r = 4 * g4; r < 4 * g4 + 4; ++r) {
-                            ex[r] = __builtin_amdgcn_exp2f(fmaf(s[r], cexp, -mc));
-                            pf[r >> 3][r & 7] = (half_t)ex[r];
+                            const float ex = __builtin_amdgcn_exp2f(fmaf(s[r], cexp, -mc));
+                            ps += ex;
+                            pf[r >> 3][r & 7] = (half_t)ex;
                         }
                         __builtin_amdgcn_sched_barrier(0);
                         if (more) sc[nxt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[nxt][g4], qf[g4], g4 == 0 ? zero16 : sc[nxt], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    // ---- O^T[d][q] += sum_key V[key][d] P[q][key]; the row sum (in tile_softmax_pv's order) rides between the MFMAs
+                    // ---- O^T[d][q] += sum_key V[key][d] P[q][key]
                     if (two_steps)
                         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vr[0][0][0]), "+v"(vr[0][0][1]), "+v"(vr[0][1][0]), "+v"(vr[0][1][1]),
                                      "+v"(vr[1][0][0]), "+v"(vr[1][0][1]), "+v"(vr[1][1][0]), "+v"(vr[1][1][1])::"memory");
                     else
                         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vr[0][0][0]), "+v"(vr[0][0][1]), "+v"(vr[0][1][0]), "+v"(vr[0][1][1])::"memory");
-                    float ps = 0.f;
 #pragma unroll
                     for (int st = 0; st < 2; ++st) {
 #pragma unroll
@@ -356,10 +356,6 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnArgs p, c
                                 }
                                 o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], o[dt], 0, 0, 0);
                             }
-                            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                            for (int r = 4 * (2 * st + dt); r < 4 * (2 * st + dt) + 4; ++r) ps += ex[r];
-                            __builtin_amdgcn_sched_barrier(0);
                         }
                     }
                     lsum += ps;
