@@ -495,6 +495,14 @@ int load_adapters(hg_ctx* c, const hg_adapter_weights* src, int layers) {
 
 inline size_t rup(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
+// Rows of the next chunk of a row-parallel call with `left` rows to go: max_chunk_rows, except that the LAST chunk absorbs a
+// tail of up to an eighth of it (100 000 rows = 32 768 + 32 768 + 34 464 instead of + 32 768 + 1 696: the four dependent GEMMs of a
+// 1 696-row chunk fill 14-56 tiles each and cost 0.12 ms for 1.7 % of the rows; workspace +5 %)
+inline int chunk_rows(const hg_ctx* c, int left) {
+    const int m = c->max_chunk_rows;
+    return left <= m + m / 8 ? left : m;
+}
+
 // hipEvent pair around one launch when its kind is being profiled
 struct ProfScope {
     hg_ctx* c;
@@ -1577,8 +1585,8 @@ int hg_cache_logits(hg_ctx* c, int slot, const float* feats, int R, float* out, 
     if (R < 0 || !feats || !out) return fail(c, HG_ERR_INVALID, "bad arguments to cache_logits");
     hipStream_t s = (hipStream_t)stream;
     HG_ON_DEVICE(c);
-    for (int r0 = 0; r0 < R; r0 += c->max_chunk_rows) {
-        const int Rc = (R - r0 < c->max_chunk_rows) ? R - r0 : c->max_chunk_rows;
+    for (int r0 = 0, Rc = 0; r0 < R; r0 += Rc) {
+        Rc = chunk_rows(c, R - r0);
         const size_t Rp = rup(Rc, 256);
         const int Np = m.has_labels ? m.Cp : m.Sp, Nout = m.has_labels ? m.C : m.S;
         int rc = ensure(c, c->h, Rp * m.K * 2);
@@ -1809,8 +1817,8 @@ int hg_vae_forward(hg_ctx* c, int slot, const float* x, const float* eps, int R,
     hipStream_t s = (hipStream_t)stream;
     HG_ON_DEVICE(c);
     const int dim = v.dim;
-    for (int r0 = 0; r0 < R; r0 += c->max_chunk_rows) {
-        const int Rc = (R - r0 < c->max_chunk_rows) ? R - r0 : c->max_chunk_rows;
+    for (int r0 = 0, Rc = 0; r0 < R; r0 += Rc) {
+        Rc = chunk_rows(c, R - r0);
         const size_t Rp = rup(Rc, 256);
         int rc = ensure(c, c->h, Rp * dim * 2);
         if (!rc) rc = ensure(c, c->att, Rp * dim * 2);
@@ -1854,8 +1862,8 @@ int hg_generator(hg_ctx* c, int slot, const float* z, int R, float* bias, void* 
     if (R < 0 || !z || !bias) return fail(c, HG_ERR_INVALID, "bad arguments to generator");
     hipStream_t s = (hipStream_t)stream;
     HG_ON_DEVICE(c);
-    for (int r0 = 0; r0 < R; r0 += c->max_chunk_rows) {
-        const int Rc = (R - r0 < c->max_chunk_rows) ? R - r0 : c->max_chunk_rows;
+    for (int r0 = 0, Rc = 0; r0 < R; r0 += Rc) {
+        Rc = chunk_rows(c, R - r0);
         const size_t Rp = rup(Rc, 256);
         int rc = ensure(c, c->att, Rp * v.dim * 2);
         if (!rc) rc = ensure(c, c->fc, Rp * v.gh * 2);
@@ -1876,8 +1884,8 @@ int hg_mlp_net(hg_ctx* c, int slot, const float* x, int R, float* out, void* str
     if (R < 0 || !x || !out) return fail(c, HG_ERR_INVALID, "bad arguments to mlp_net");
     hipStream_t s = (hipStream_t)stream;
     HG_ON_DEVICE(c);
-    for (int r0 = 0; r0 < R; r0 += c->max_chunk_rows) {
-        const int Rc = (R - r0 < c->max_chunk_rows) ? R - r0 : c->max_chunk_rows;
+    for (int r0 = 0, Rc = 0; r0 < R; r0 += Rc) {
+        Rc = chunk_rows(c, R - r0);
         const size_t Rp = rup(Rc, 256);
         int rc = ensure(c, c->h, Rp * m.in * 2);
         if (!rc) rc = ensure(c, c->att, Rp * m.hid * 2);
