@@ -11,7 +11,11 @@ static constexpr int ROWB = HD * 2;      // bytes per K/V row in LDS
 static constexpr int TILEB = 32 * ROWB;  // bytes per 32-key tile
 
 __device__ __forceinline__ int swz_k(int row) { return (row >> 1) & 7; }          // b128 row reads
-__device__ __forceinline__ int swz_v(int row) { return ((row >> 1) & 1) << 2; }   // tr_b16 reads
+// V rows: bit 2 from (row >> 1) & 1 keeps the transposing reads conflict-free (a 32-lane group reads 64 bytes of each of 4 consecutive rows:
+// rows r and r + 2 must sit in different halves of the 128 bytes); the low two bits from (row >> 2) & 3 are constant inside such a group of
+// 4 rows (they only permute the 16-byte chunks inside a 64-byte half) and spread the 16 rows of a register-fed ds_write_b64 (hg_qkv_attn.hip:
+// one row per lane) over all 16 slots of the bank row instead of 4
+__device__ __forceinline__ int swz_v(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }   // tr_b16 reads
 
 // One 32-key tile of the online softmax for this wave's 32 queries (lane = query qcol, key half hh), in two parts so
 // that a caller can reuse its Q registers in between: tile_scores() S^T = K_tile Q^T; tile_softmax_pv()
@@ -79,10 +83,11 @@ __device__ __forceinline__ void tile_softmax_pv(const char* vb, const int (&v_of
         fp16x4_t vr[2][2];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
+            // the second read (keys + 8): swz_v flips bit 1 of the chunk index there = bit 5 of the byte address
             const unsigned va = (unsigned)(size_t)(HG_LDS const char*)(vb + sstep * (16 * ROWB) + v_off[dt]);
-            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024"
+            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3 offset:1024"
                          : "=&v"(vr[dt][0]), "=&v"(vr[dt][1])
-                         : "v"(va)
+                         : "v"(va), "v"(va ^ 32u)
                          : "memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vr[0][0]), "+v"(vr[0][1]), "+v"(vr[1][0]), "+v"(vr[1][1])::"memory");

@@ -289,9 +289,11 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnArgs p, c
                         if (st == 1 && !two_steps) break;
 #pragma unroll
                         for (int dt = 0; dt < 2; ++dt) {      // (tile and step offset as immediates: < 64 KiB)
-                            asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                            // (the second read, keys + 8: swz_v flips bit 1 of the chunk index there = bit 5 of the byte address)
+                            asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%5"
                                          : "=&v"(vr[st][dt][0]), "=&v"(vr[st][dt][1])
-                                         : "v"(v_addr[dt]), "n"(kt * TILEB + st * (16 * ROWB)), "n"(kt * TILEB + st * (16 * ROWB) + 1024)
+                                         : "v"(v_addr[dt]), "v"(v_addr[dt] ^ 32u), "n"(kt * TILEB + st * (16 * ROWB)),
+                                           "n"(kt * TILEB + st * (16 * ROWB) + 1024)
                                          : "memory");
                         }
                     }
