@@ -139,7 +139,8 @@ struct hg_ctx {
     int opt_adapter_fold = 1;    // adapter folded into the block's own QKV / out-proj GEMMs (0: separate up_proj GEMM)
     int opt_stream_hilo = 1;     // residual stream as centre + hi + lo (two fp16 halves) between the folded blocks (0: fp32)
     int opt_qkv_attn = 1;        // in_proj + attention as one kernel, q / k / v kept in LDS (vision tower, folded blocks; 0: two kernels)
-    int opt_qkv_attn_min_seq = 64;   // ... from this many sequences per call on (fewer: not enough items to fill the chip)
+    int opt_qkv_attn_min_seq = 32;   // ... from this many sequences per call on, and where its last round of items is filled well
+                                     // enough (qkv_attn_pays; qkv_attn = 2: wherever the shapes allow)
     int opt_qkv_attn_gsz = 0;    // head pairs per XCD group of that kernel (0 = all)
     // sticky device->host flag (host-mapped): set by clamp_eot when a caller-supplied text truncation was shorter than
     // max(EOT)+1 (a stale host memo); reported as HG_ERR_INVALID by the next text call
@@ -686,7 +687,8 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
     }
     // blocks whose in_proj and attention run as one kernel (option qkv_attn): folded LayerNorm, no adapter in the block's
     // GEMMs, a sequence per row tile (192 < L <= 208), enough sequences to fill the chip
-    const bool qa_on = fuse && !causal && c->opt_qkv_attn && n_seq >= c->opt_qkv_attn_min_seq && qkv_attn_ok(n_seq, L, D, heads, D);
+    const bool qa_on = fuse && !causal && c->opt_qkv_attn && n_seq >= c->opt_qkv_attn_min_seq && qkv_attn_ok(n_seq, L, D, heads, D) &&
+                       (c->opt_qkv_attn == 2 || qkv_attn_pays(n_seq, heads, 0));
     auto qa_block = [&](size_t i, bool row0_last_blk) { return qa_on && !row0_last_blk && kmode[i] == 0 && blocks[i].wp_qkv != nullptr; };
     int rln_i = 0;                  // index of the next LayerNorm-emitting residual GEMM
     bool x_is_hilo = false;         // the stream currently lives in (h, xlo, muc), not in x
@@ -944,7 +946,7 @@ int hg_set_option(hg_ctx* c, const char* key, int value) {
     else if (k == "adapter_fuse") c->opt_adapter_fuse = value != 0;
     else if (k == "adapter_fold") c->opt_adapter_fold = value != 0;
     else if (k == "stream_hilo") c->opt_stream_hilo = value != 0;
-    else if (k == "qkv_attn") c->opt_qkv_attn = value != 0;
+    else if (k == "qkv_attn") { if (value >= 0 && value <= 2) c->opt_qkv_attn = value; }
     else if (k == "qkv_attn_min_seq") { if (value >= 1) c->opt_qkv_attn_min_seq = value; }
     else if (k == "qkv_attn_gsz") { if (value >= 0 && value <= 6) c->opt_qkv_attn_gsz = value; }
     else return fail(c, HG_ERR_INVALID, "unknown option '%s'", key);

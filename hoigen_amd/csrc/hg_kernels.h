@@ -113,6 +113,8 @@ struct QkvAttnArgs {
 };
 // 192 < L <= 208, D = 64 * heads, heads even, D / 64 a multiple of 3 (ViT-B/16: L = 197, D = 768)
 bool qkv_attn_ok(int n_seq, int L, int D, int heads, int lda);
+// speed only: is the last round of (sequence, head pair) items filled well enough (n_cu <= 0: 256)
+bool qkv_attn_pays(int n_seq, int heads, int n_cu);
 // W [3D, D] fp16 (LayerNorm-folded), bias / cs [3D] -> Wp [3D * D] fp16 in fragment order, bcs [heads / 2][768] fp32
 hipError_t launch_pack_qkv(const half_t* W, const float* bias, const float* cs, half_t* Wp, float* bcs, int D, int heads,
                            hipStream_t s);

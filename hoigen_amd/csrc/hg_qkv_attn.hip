@@ -480,6 +480,16 @@ bool qkv_attn_ok(int n_seq, int L, int D, int heads, int lda) {
     return true;
 }
 
+// Whether the one kernel beats the two it replaces at this batch: its time is (items / CUs rounded UP) x one item (37 us), so it
+// wants its last round well filled - measured (profiles/r04_qkv_attn.txt, sequences: fused / separate us): 32: 43 / 61, 43: 73 / 80,
+// 64: 75 / 77, 86: 109 / 105, 128: 122 / 139, 171: 190 / 174, 192: 191 / 199, 256: 222 / 245.  Results are bit-identical either way.
+bool qkv_attn_pays(int n_seq, int heads, int n_cu) {
+    if (n_cu <= 0) n_cu = 256;
+    const long items = (long)n_seq * (heads / 2);
+    const long rounds = (items + n_cu - 1) / n_cu;
+    return rounds <= 1 || items * 100 >= rounds * n_cu * 88;
+}
+
 hipError_t launch_qkv_attn(const QkvAttnArgs& a_in, hipStream_t s) {
     QkvAttnArgs a = a_in;
     if (!qkv_attn_ok(a.n_seq, a.L, a.D, a.heads, a.lda) || !a.x16 || !a.wp || !a.bcs || !a.mr || !a.out) return hipErrorInvalidValue;

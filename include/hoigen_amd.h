@@ -242,9 +242,9 @@ int hg_vae_loss(hg_ctx*, const float* recon, const float* x, const float* mean, 
  *                      centre + two fp16 halves (the centred copy the GEMMs read + its remainder); 0: as fp32 throughout
  *   "qkv_attn"        [HG_QKV_ATTN]        1: in the LayerNorm-folded blocks of the vision tower in_proj and attention run as ONE kernel
  *                      (hoigen_amd/csrc/hg_qkv_attn.hip: q, k, v stay in LDS; 192 < tokens <= 208, i.e. ViT-B/16); 0: two kernels with the
- *                      qkv matrix in HBM between them.  Bit-identical results either way.
- *   "qkv_attn_min_seq" [HG_QKV_ATTN_MIN_SEQ] ... from this many sequences per call on (default 64: below, the (sequence, head pair)
- *                      items do not fill the chip)
+ *                      qkv matrix in HBM between them; 2: the one kernel wherever the shapes allow (1 also asks that the last round
+ *                      of its (sequence, head pair) items is well filled: speed only).  Bit-identical results either way.
+ *   "qkv_attn_min_seq" [HG_QKV_ATTN_MIN_SEQ] ... from this many sequences per call on (default 32)
  *   "qkv_attn_gsz"    [HG_QKV_ATTN_GSZ]    head pairs per XCD group of that kernel (0 = all six side by side; speed only)
  *   "chunk_rows"      [HG_CHUNK_ROWS]      rows per VAE / mlp_net / cache-logits chunk (>= 256; default 32768; the last chunk of a
  *                      call absorbs a tail of up to an eighth of it)

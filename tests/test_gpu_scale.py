@@ -54,6 +54,33 @@ def test_config5_batch2048_equals_eight_chunks_of_256(fullA):
     assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-3      # reference crops inside the big batch
 
 
+
+def test_fused_in_proj_attention_is_bit_identical_inside_encode_image(fullA):
+    """Option qkv_attn (hg_qkv_attn.hip: in_proj + attention as one kernel, q / k / v in LDS): encode_image with it forced on (2),
+    chosen by batch (1, the default) and off (0) gives the SAME bits at batch 256 (six full rounds of items), 171 (the default
+    picks the two kernels there) and 40 (fewer items than CUs), with every row of the last block computed and with the class rows
+    only; the reference's golden crops ride inside the batch."""
+    d = dev()
+    gen = torch.Generator(device=d).manual_seed(256)
+    crops = torch.randn(256, 3, 224, 224, device=d, generator=gen)
+    crops[100:104] = torch.from_numpy(synth.crops(4, 224, seed=1234)).to(d)
+    ref = np.load(f"{G}/g2_vitb16_image.npz")["encode_image"]
+    try:
+        for row0 in (1, 0):
+            fullA.visual.set_option("last_block_row0", row0)
+            for n in (256, 171, 40):
+                outs = []
+                for mode in (2, 1, 0):
+                    fullA.visual.set_option("qkv_attn", mode)
+                    outs.append(fullA.encode_image(crops[256 - n:]))
+                assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2]), (row0, n)
+        fullA.visual.set_option("qkv_attn", 2)
+        got = fullA.encode_image(crops)[100:104].float().cpu().numpy()
+        assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-3
+    finally:
+        fullA.visual.set_option("qkv_attn", 1)
+        fullA.visual.set_option("last_block_row0", 1)
+
 def test_config4_vae_100k_rows_equals_chunks():
     """BASELINE config 4: 100 000 rows through Encoder -> reparameterise -> Generator in one call (crosses the
     32 768-row chunk boundary three times) == separate calls on the row ranges; ragged ranges included."""
