@@ -16,7 +16,10 @@ prev={}
 for r in rows:
     k=re.sub(r'.*(gemm_\w+<[^>]*>).*',r'\1',r['Kernel_Name'])
     # residual kernels alternate out_proj / c_proj: split by grid-independent parity of occurrence
-    if '10>' in k or '10,' in k:
+    if '<10, 2>' in r['Kernel_Name']:      # hi / lo stream: the 21 middle launches of a step alternate c_proj, out_proj, c_proj, ...
+        n=prev.get(k,0); prev[k]=n+1
+        k+= ' c_proj' if (n%21)%2==0 else ' out_proj'
+    elif '10>' in k or '<10, 0>' in r['Kernel_Name']:
         n=prev.get(k,0); prev[k]=n+1
         k+= ' out_proj' if (n%23)%2==0 else ' c_proj'   # 12 out_proj + 11 c_proj per step, alternating
     agg[k+' '+r['Counter_Name']].append(float(r['Counter_Value']))
