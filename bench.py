@@ -492,13 +492,19 @@ def run(args):
         bytes_l = sum(kernel_row(*r[:4])[2] for r in live) / max(1, len(live))
         ms_l = sum(r[4] for r in live) / max(1, len(live))
         ach = flops_l / ms_l / 1e9 if ms_l > 0 else 0.0
-        traffic = None
+        traffic = step_traffic = None
         tpath = os.path.join(HERE, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"kind{dom_kind}_hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get(f"kind{dom_kind}_hbm_bytes_per_launch")
+                # HBM-side bytes of the whole step (FETCH_SIZE x 2 + WRITE_SIZE over every kernel of one all-rows step), from the
+                # same PMC passes (tools/gpu_energy_ab.sh); the default configuration's entry
+                st = tj.get("step_total_MB", {})
+                key = next((k for k in st if "(default)" in k and "stagger" in k), next((k for k in st if "(default)" in k), None))
+                step_traffic = int(st[key] * 1e6) if key else None
             except Exception:
-                traffic = None
+                traffic = step_traffic = None
         ps = sorted(per_step)
         pct = lambda q: round(ps[min(len(ps) - 1, int(q * len(ps)))], 4)
         e2e = value / world * FLOPS_PER_CROP / 1e12
@@ -521,7 +527,7 @@ def run(args):
                                    f"({by_kind[dom_kind]:.3f} of {sum(by_kind.values()):.3f} ms of GEMM+attention time), "
                                    f"{dom_launches} launches per step, shapes (M,N,K) {shapes}",
                          "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "step_traffic": step_traffic,
                          "avg_kernel_ms": round(ms_l, 4), "avg_gflop_per_launch": round(flops_l / 1e9, 2),
                          "launches_timed": len(live),
                          "algorithmic_hbm_bytes_per_launch": int(bytes_l),
