@@ -5,4 +5,4 @@ timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/final_gputests.log
 python bench.py > gpurun_out/bench_final.log 2>&1; tail -1 gpurun_out/bench_final.log | cut -c1-300
 bash tools/gpu_trace_headline.sh > gpurun_out/trace_headline.log 2>&1; tail -9 gpurun_out/trace_headline.log | cut -c1-200
 cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/prof_full && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_full -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $R/gpurun_out/bench_prof_full.log 2>&1
-cd $R; f=$(find gpurun_out/prof_full -name "*kernel_stats.csv" | head -1); test -n "$f" && head -10 "$f" | cut -c1-160
+cd $R; f=$(ls -t gpurun_out/prof_full/*/*kernel_stats.csv | head -1); test -n "$f" && head -10 "$f" | cut -c1-160
