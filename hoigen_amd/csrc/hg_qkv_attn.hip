@@ -48,7 +48,7 @@ namespace {
 constexpr int QA_RB = SQ_RB;                       // 16-row blocks of a sequence tile
 constexpr int QA_NCB = SQ_NCB;                     // 16-column blocks per wave
 constexpr int QA_ASTG = SQ_ASTG;                   // one A stage = one Q / K / V matrix: 208 rows x 128 B
-constexpr int QA_ATT = SQ_S12;                     // stages 1 and 2 of the K loop = the attention operands
+[[maybe_unused]] constexpr int QA_ATT = SQ_S12;                     // stages 1 and 2 of the K loop = the attention operands
 constexpr int QA_ATT_BYTES = SQ_S12_BYTES;         // 3 x QA_ASTG + slack (tile 6 of Q / K reads 16 rows into the next matrix)
 constexpr int QA_BCS = SQ_END;                     // bias'[384] | cs[384] in tile column order
 constexpr int QA_MR = QA_BCS + 2 * 384 * 4;
