@@ -1,5 +1,5 @@
 """Diagnostics: c_fc + QuickGELU on sequence tiles (hg_gemm_seq.hip) against the 256 x 256 ring, ViT-B/16 shape (256 x 197 rows,
-N = 3072, K = 768; QKV = "8 2304"), hipEvent pairs around every launch, alternating.  GSZ="0 4 2": XCD group sizes to time."""
+N = 3072, K = 768; QKV = "8 2304"), hipEvent pairs around every launch, alternating.  GSZ="0 4 2": XCD group sizes to time; STAG="0 18000:3": start staggers (cycles:phases)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -35,5 +35,8 @@ for rnd in range(int(os.environ.get("ROUNDS", 3))):
     line = "round %d: ring: median %.1f min %.1f us |" % ((rnd,) + timed(2))
     for gsz in [int(x) for x in os.environ.get("GSZ", "0").split()]:
         L_.hg_set_option(ctx, b"seq_fc_gsz", gsz)
-        line += " seq gsz %d: median %.1f min %.1f us |" % ((gsz,) + timed(1000 + L))
+        for st in os.environ.get("STAG", "0").split():
+            cyc, ph = ([int(v) for v in st.split(":")] + [0])[:2]
+            L_.hg_set_option(ctx, b"seq_fc_stagger", (cyc << 4) | ph)
+            line += " seq gsz %d stag %s: median %.1f min %.1f us |" % ((gsz, st) + timed(1000 + L))
     print(line, flush=True)

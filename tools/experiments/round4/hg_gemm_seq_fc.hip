@@ -31,7 +31,7 @@ static_assert(GS_LDS <= 160 * 1024, "LDS budget");
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_seq_kernel(const GemmArgs p, const half_t* __restrict__ wp, const int n_seq, const int L,
-                                                          const unsigned a_bytes, const int gsz, const int mode) {
+                                                          const unsigned a_bytes, const int gsz, const int stagger, const int mode) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // timing-experiment switches (HG_GS_MODE bits: 2 no MFMA in the K loop, 4 no epilogue, 8 no operand DMA; wrong results) exist only
     // in a -DHG_EXPERIMENTS build
@@ -58,6 +58,16 @@ __global__ __launch_bounds__(512, 2) void gemm_seq_kernel(const GemmArgs p, cons
     ns = ns < 0 ? 0 : (ns > spx ? spx : ns);
     const int nx = ns * PN;
     if (idx >= nx) return;
+    // De-phased epilogues: every item takes the same time and every CU owns the same number, so all CUs would store their 160 KB
+    // tile at the same moment - HBM idles during the K loops and saturates during the epilogues, and vmcnt (in issue order) makes
+    // the next item's first operand wait stand behind the whole burst.  The workgroups of consecutive sequences start `stagger >> 4`
+    // cycles apart in `stagger & 15` phases (workgroups on the panels of one sequence stay in step: they share its rows in L2).
+    if ((stagger & 15) > 1) {
+        const int ph = (idx / gsz) % (stagger & 15);
+        const long long d = (long long)ph * (stagger >> 4);
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while ((long long)(__builtin_amdgcn_s_memtime() - t0) < d) __builtin_amdgcn_s_sleep(32);
+    }
     auto decode = [&](int e, int& seq, int& pn) {
         const int per = ns * gsz;
         const int grp = e / per, rem = e - grp * per;
@@ -223,7 +233,7 @@ bool gemm_seq_ok(int epi, const GemmArgs& a, int n_seq, int L) {
 }
 
 template <int EPI>
-static hipError_t launch_seq_t(const GemmArgs& a, const half_t* wp, int n_seq, int L, int gsz, hipStream_t s) {
+static hipError_t launch_seq_t(const GemmArgs& a, const half_t* wp, int n_seq, int L, int gsz, int stagger, hipStream_t s) {
     static bool attr_set_d[HG_MAX_DEVICES] = {};
     static int n_cu_d[HG_MAX_DEVICES];
     const int dev_i = current_device_index();
@@ -249,14 +259,14 @@ static hipError_t launch_seq_t(const GemmArgs& a, const half_t* wp, int n_seq, i
 #else
     constexpr int mode = 0;
 #endif
-    hipLaunchKernelGGL((gemm_seq_kernel<EPI>), dim3(grid), dim3(512), GS_LDS, s, a, wp, n_seq, L, a_bytes, gsz, mode);
+    hipLaunchKernelGGL((gemm_seq_kernel<EPI>), dim3(grid), dim3(512), GS_LDS, s, a, wp, n_seq, L, a_bytes, gsz, stagger, mode);
     return hipGetLastError();
 }
 
-hipError_t launch_gemm_seq(int epi, const GemmArgs& a, const half_t* wp, int n_seq, int L, int gsz, hipStream_t s) {
+hipError_t launch_gemm_seq(int epi, const GemmArgs& a, const half_t* wp, int n_seq, int L, int gsz, int stagger, hipStream_t s) {
     if (!wp || !gemm_seq_ok(epi, a, n_seq, L)) return hipErrorInvalidValue;
-    return epi == EPI_LN_BIAS_QGELU_F16 ? launch_seq_t<EPI_LN_BIAS_QGELU_F16>(a, wp, n_seq, L, gsz, s)
-                                        : launch_seq_t<EPI_LN_BIAS_F16>(a, wp, n_seq, L, gsz, s);
+    return epi == EPI_LN_BIAS_QGELU_F16 ? launch_seq_t<EPI_LN_BIAS_QGELU_F16>(a, wp, n_seq, L, gsz, stagger, s)
+                                        : launch_seq_t<EPI_LN_BIAS_F16>(a, wp, n_seq, L, gsz, stagger, s);
 }
 
 }  // namespace hg
