@@ -347,7 +347,7 @@ def kernel_row(kind, M, N, K):
         return f"c_fc + QuickGELU (N={N}, K={K})", fl, M * K * 2 + w + M * N * 2
     if kind in (3, 10):
         # fp32 stream: read + write 4 B each (+ the 2-byte centred copy for the next LayerNorm-folded GEMM); stream held as
-        # centre + hi + lo (option stream_hilo): hi IS the copy - 4 B in, 4 B out (RLN_STREAM_BYTES: mean over the step's launches)
+        # centre + hi + lo (option stream_hilo): hi IS the copy - 3 B in, 3 B out with lo as bf8 (RLN_STREAM_BYTES: mean over the step's launches)
         stream = RLN_STREAM_BYTES if kind == 10 else 8.0
         nm = "out_proj" if K == N else "c_proj"
         return f"{nm} + residual (N={N}, K={K})", fl, M * K * 2 + w + M * N * stream
@@ -451,8 +451,12 @@ def run(args):
     hilo = ctypes.c_int32(0)
     _lib.lib().hg_get_option(model.visual._ctx.handle, b"stream_hilo", ctypes.byref(hilo))
     if hilo.value and args.batch * 197 >= 512:
-        # 23 such launches per all-rows step: the first reads fp32 and writes hi + lo (8 B), the last reads hi + lo and writes fp32 + copy (10 B)
-        RLN_STREAM_BYTES = (22 * 8.0 + 10.0) / 23
+        # 23 such launches per all-rows step, lo = b bytes (bf8: 1, the default build; fp16: 2): 21 read and write hi + lo (4 + 2b), the first
+        # reads fp32 and writes hi + lo (6 + b), the last reads hi + lo and writes fp32 + copy (8 + b)
+        lo_bits = ctypes.c_int32(16)
+        _lib.lib().hg_get_option(model.visual._ctx.handle, b"stream_lo_bits", ctypes.byref(lo_bits))
+        b = lo_bits.value / 8.0
+        RLN_STREAM_BYTES = (21 * (4 + 2 * b) + (6 + b) + (8 + b)) / 23
     # two more untimed steps with every GEMM / attention launch bracketed by events: the per-kernel table, and which
     # kernel the live `roofline` measurement of the timed region follows
     PROF_STEPS = 2

@@ -137,7 +137,7 @@ struct hg_ctx {
     int opt_ln_fuse = 1;         // LayerNorm folded into the GEMMs where the shapes allow
     int opt_adapter_fuse = 1;    // ... also behind the instance adapters (variant C)
     int opt_adapter_fold = 1;    // adapter folded into the block's own QKV / out-proj GEMMs (0: separate up_proj GEMM)
-    int opt_stream_hilo = 1;     // residual stream as centre + hi + lo (two fp16 halves) between the folded blocks (0: fp32)
+    int opt_stream_hilo = 1;     // residual stream as centre + hi + lo (fp16 copy + bf8 remainder) between the folded blocks (0: fp32)
     int opt_qkv_attn = 1;        // in_proj + attention as one kernel, q / k / v kept in LDS (vision tower, folded blocks; 0: two kernels)
     int opt_qkv_attn_min_seq = 32;   // ... from this many sequences per call on, and where its last round of items is filled well
                                      // enough (qkv_attn_pays; qkv_attn = 2: wherever the shapes allow)
@@ -665,8 +665,8 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
     }
     if (pre_w && trace) HG_HIP(launch_copy_rows(x, trace, n_seq, L, D, s));
     // Residual stream as centre + hi + lo between the LayerNorm-emitting residual GEMMs (GemmArgs::hl; option stream_hilo):
-    // hi IS the centred fp16 copy those GEMMs write anyway, lo its fp16 remainder - 8 instead of 10 bytes per element through
-    // every such epilogue and a third fewer partial-line stores.  The first of them reads the fp32 stream (ln_pre wrote it),
+    // hi IS the centred fp16 copy those GEMMs write anyway, lo its remainder as bf8 (HG_LO8; fp16 otherwise) - 6 (8) instead of 10
+    // bytes per element through every such epilogue and a third fewer partial-line stores.  The first of them reads the fp32 stream (ln_pre wrote it),
     // the last one writes fp32 again (the plain last c_proj / the class-rows path / ln_post read it); nothing in between
     // touches x.  Variant A only (the adapters rewrite the stream), and only where the GEMMs run on gemm_ring2.
     const bool row0_plan = row0_out && row0_env && !adapters;
@@ -962,6 +962,7 @@ int hg_get_option(hg_ctx* c, const char* key, int* value) {
     else if (k == "adapter_fuse") *value = c->opt_adapter_fuse;
     else if (k == "adapter_fold") *value = c->opt_adapter_fold;
     else if (k == "stream_hilo") *value = c->opt_stream_hilo;
+    else if (k == "stream_lo_bits") *value = HG_LO8 ? 8 : 16;      // read-only: how the build holds the low half
     else if (k == "qkv_attn") *value = c->opt_qkv_attn;
     else if (k == "qkv_attn_min_seq") *value = c->opt_qkv_attn_min_seq;
     else if (k == "qkv_attn_gsz") *value = c->opt_qkv_attn_gsz;

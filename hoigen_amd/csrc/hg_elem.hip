@@ -500,7 +500,14 @@ __global__ void copy_rows_hilo_kernel(const half_t* __restrict__ hi, const half_
     const int piece = (r >> 6) * 4 + (cc >> 7) * 2 + ((cc >> 4) & 1);
     const int lane = ((cc & 15) >> 2) * 16 + (r & 15);
     const size_t lo_i = (((tile * 8 + wave) * 8 + piece) * 64 + lane) * 8 + ((r & 31) >> 4) * 4 + (cc & 3);
-    out[i] = (muc[m] + (float)hi[m * D + n]) + (float)lo[lo_i];
+    float lof;
+    if constexpr (HG_LO8) {      // bf8 (e5m2) = the top byte of an fp16
+        const unsigned short b = reinterpret_cast<const unsigned char*>(lo)[lo_i];
+        lof = (float)__builtin_bit_cast(half_t, (unsigned short)(b << 8));
+    } else {
+        lof = (float)lo[lo_i];
+    }
+    out[i] = (muc[m] + (float)hi[m * D + n]) + lof;
 }
 hipError_t launch_copy_rows_hilo(const half_t* hi, const half_t* lo, const float* muc, float* out, int B, int row_stride, int D,
                                  hipStream_t s) {

@@ -41,8 +41,9 @@ namespace hg {
 
 // HL (EPI_RESID_LN_F32 only): how the residual stream is held on the way in / out (GemmArgs::hl): 0 fp32 / fp32, 1 fp32 /
 // hi + lo, 2 hi + lo / hi + lo, 3 hi + lo / fp32.  hi = the centred fp16 copy (row-major: the next GEMM's operand), lo = the
-// fp16 remainder in tile-fragment order: piece (ha, hb, g2) of a wave = this lane's two row tiles f = 0, 1 (2 x 8 B), 64 lanes
-// x 16 B contiguous - whole lines in, whole lines out.  8 instead of 10 bytes per element and 16 instead of 24 partial-line
+// remainder (x - centre) - hi in tile-fragment order: piece (ha, hb, g2) of a wave = this lane's two row tiles f = 0, 1 side by
+// side, 64 lanes contiguous - whole lines in, whole lines out.  lo is bf8 (HG_LO8, hg_kernels.h: 2 x 4 B per lane; 6 bytes per
+// element through the epilogue) or fp16 (2 x 8 B; 8 bytes) instead of the fp32 stream's 10, and 16 instead of 24 partial-line
 // store instructions per wave and tile.
 template <int EPI, int HL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int tiles_n, const int n_tiles,
@@ -315,7 +316,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
         float mucv[IN_HL ? 2 : 1][IN_HL ? 2 : 1];     // centre the hi / lo being read were written with
         // lo piece (ha, hb, g2) of this wave and tile: 64 lanes x 16 B
         auto lo_ptr = [&](int tm_, int tn_, int ha, int hb, int g2) {
-            return p.lo + ((((size_t)tm_ * tiles_n + tn_) * 8 + wave) * 8 + (ha * 4 + hb * 2 + g2)) * 512 + lane * 8;
+            return p.lo + ((((size_t)tm_ * tiles_n + tn_) * 8 + wave) * 8 + (ha * 4 + hb * 2 + g2)) * (HG_LO8 ? 256 : 512) +
+                   lane * (HG_LO8 ? 4 : 8);
         };
         // One K-tile.  KIND: 0 middle, 1 first of a tile (the previous epilogue's stores may be pending), 2 / 3 / 4 the
         // third-to-last, second-to-last and last K-tile of a tile: only there the refills (A at distance 2, W at
@@ -343,7 +345,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                             for (int g2 = 0; g2 < 2; ++g2) {
                                 xhi[ha][hb][g2] = *reinterpret_cast<const u32x4_hl*>(
                                     p.out2 + (size_t)mp * p.ld2 + n0 + hb * 128 + wn * 32 + g2 * 16 + 4 * (qq & ~1));
-                                xlo[ha][hb][g2] = *reinterpret_cast<const u32x4_hl*>(lo_ptr(tm, tn, ha, hb, g2));
+                                if constexpr (HG_LO8) {
+                                    typedef unsigned u32x2_hl __attribute__((ext_vector_type(2)));
+                                    const u32x2_hl l8 = *reinterpret_cast<const u32x2_hl*>(lo_ptr(tm, tn, ha, hb, g2));
+                                    xlo[ha][hb][g2] = u32x4_hl{l8[0], l8[1], 0u, 0u};
+                                } else {
+                                    xlo[ha][hb][g2] = *reinterpret_cast<const u32x4_hl*>(lo_ptr(tm, tn, ha, hb, g2));
+                                }
                             }
 #pragma unroll
                         for (int f = 0; f < 2; ++f) {
@@ -463,7 +471,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
             for (int ha = 0; ha < 2; ++ha) {
                 half4 h16[2][2][2];                         // [f][hb][g2]: the new copy (hi)
                 half4 l16[OUT_HL ? 2 : 1][OUT_HL ? 2 : 1][OUT_HL ? 2 : 1];
-                half4 hin[IN_HL ? 2 : 1][IN_HL ? 2 : 1][IN_HL ? 2 : 1], lin[IN_HL ? 2 : 1][IN_HL ? 2 : 1][IN_HL ? 2 : 1];
+                unsigned l8[OUT_HL ? 2 : 1][OUT_HL ? 2 : 1][OUT_HL ? 2 : 1];      // HG_LO8: the remainder as four bf8 (e5m2)
+                half4 hin[IN_HL ? 2 : 1][IN_HL ? 2 : 1][IN_HL ? 2 : 1];
+                f32x4 lin[IN_HL ? 2 : 1][IN_HL ? 2 : 1][IN_HL ? 2 : 1];
                 if constexpr (IN_HL) {
                     // the copy was stored with the row tiles f = 0, 1 paired through v_permlane16_swap (below); the same
                     // exchange gives every lane its own two row tiles back; the lo piece holds them side by side
@@ -476,8 +486,20 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                             const auto s1 = __builtin_amdgcn_permlane16_swap(o[1], o[3], false, false);
                             hin[0][hb][g2] = __builtin_bit_cast(half4, u32x2{(unsigned)s0[0], (unsigned)s1[0]});
                             hin[1][hb][g2] = __builtin_bit_cast(half4, u32x2{(unsigned)s0[1], (unsigned)s1[1]});
-                            lin[0][hb][g2] = __builtin_bit_cast(half4, u32x2{l[0], l[1]});
-                            lin[1][hb][g2] = __builtin_bit_cast(half4, u32x2{l[2], l[3]});
+                            if constexpr (HG_LO8) {
+#pragma unroll
+                                for (int f = 0; f < 2; ++f) {
+                                    const auto a = __builtin_amdgcn_cvt_pk_f32_bf8((int)l[f], false);
+                                    const auto b = __builtin_amdgcn_cvt_pk_f32_bf8((int)l[f], true);
+                                    lin[f][hb][g2] = f32x4{a[0], a[1], b[0], b[1]};
+                                }
+                            } else {
+#pragma unroll
+                                for (int f = 0; f < 2; ++f) {
+                                    const half4 lh = __builtin_bit_cast(half4, u32x2{l[2 * f], l[2 * f + 1]});
+                                    lin[f][hb][g2] = f32x4{(float)lh[0], (float)lh[1], (float)lh[2], (float)lh[3]};
+                                }
+                            }
                         }
                 }
 #pragma unroll
@@ -494,7 +516,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                             if constexpr (IN_HL) {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e)
-                                    xin[e] = (mucv[ha][f] + (float)hin[f][hb][g2][e]) + (float)lin[f][hb][g2][e];
+                                    xin[e] = (mucv[ha][f] + (float)hin[f][hb][g2][e]) + lin[f][hb][g2][e];
                             } else {
                                 xin = xres[ha][hb][f][g2];
                             }
@@ -504,12 +526,19 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                                 if (INTERIOR || m < p.M)
                                     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v[hb][g2];
                             }
+                            float rem[4];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const float d = v[hb][g2][e] - muv[ha][f];
                                 const half_t hh = (half_t)d;
                                 h16[f][hb][g2][e] = hh;
-                                if constexpr (OUT_HL) l16[f][hb][g2][e] = (half_t)(d - (float)hh);
+                                rem[e] = d - (float)hh;
+                                if constexpr (OUT_HL && !HG_LO8) l16[f][hb][g2][e] = (half_t)rem[e];
+                            }
+                            if constexpr (OUT_HL && HG_LO8) {
+                                int w8 = __builtin_amdgcn_cvt_pk_bf8_f32(rem[0], rem[1], 0, false);
+                                w8 = __builtin_amdgcn_cvt_pk_bf8_f32(rem[2], rem[3], w8, true);
+                                l8[f][hb][g2] = (unsigned)w8;
                             }
                         }
                     sum = sum_rows(sum);
@@ -544,8 +573,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                         const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
                         if (INTERIOR || m < p.M) *reinterpret_cast<u32x4*>(out2 + (size_t)m * p.ld2 + nb + 4 * (q & ~1)) = o;
                         if constexpr (OUT_HL) {      // the remainder: this lane's two row tiles side by side, the wave's piece contiguous
-                            const u32x2 lx = __builtin_bit_cast(u32x2, l16[0][hb][g2]), ly = __builtin_bit_cast(u32x2, l16[1][hb][g2]);
-                            *reinterpret_cast<u32x4*>(lo_ptr(tm, tn, ha, hb, g2)) = u32x4{lx[0], lx[1], ly[0], ly[1]};
+                            if constexpr (HG_LO8) {
+                                *reinterpret_cast<u32x2*>(lo_ptr(tm, tn, ha, hb, g2)) = u32x2{l8[0][hb][g2], l8[1][hb][g2]};
+                            } else {
+                                const u32x2 lx = __builtin_bit_cast(u32x2, l16[0][hb][g2]), ly = __builtin_bit_cast(u32x2, l16[1][hb][g2]);
+                                *reinterpret_cast<u32x4*>(lo_ptr(tm, tn, ha, hb, g2)) = u32x4{lx[0], lx[1], ly[0], ly[1]};
+                            }
                         }
                     }
             }

@@ -33,6 +33,13 @@ enum Epilogue : int {
     EPI_SCALE_RESID_LN_F32 = 12
 };
 
+// Low half of a residual stream held as centre + hi + lo (GemmArgs::hl): 1 = bf8 (e5m2: the top byte of the fp16 remainder, rounded to
+// nearest even by v_cvt_pk_bf8_f32; 13-14 bits of x - centre, 6 bytes per element through a residual epilogue), 0 = fp16 (22 bits,
+// 8 bytes).  One of the two is built; hg_get_option("stream_lo_bits") reports which.
+#ifndef HG_LO8
+#define HG_LO8 1
+#endif
+
 struct GemmArgs {
     const half_t* A;   // [M, lda] (K contiguous)
     const half_t* W;   // [N, K]

@@ -239,7 +239,8 @@ int hg_vae_loss(hg_ctx*, const float* recon, const float* x, const float* mean, 
  *   "adapter_fuse"    [HG_ADAPTER_FUSE]    1: ... also around the instance adapters of variant C
  *   "adapter_fold"    [HG_ADAPTER_FOLD]    1: adapter update folded into the block's own GEMMs; 0: separate up_proj GEMM
  *   "stream_hilo"     [HG_STREAM_HILO]     1: between the LayerNorm-folded blocks of variant A the residual stream is held as
- *                      centre + two fp16 halves (the centred copy the GEMMs read + its remainder); 0: as fp32 throughout
+ *                      centre + hi + lo (the centred fp16 copy the GEMMs read + its remainder as bf8; fp16 in a -DHG_LO8=0 build:
+ *                      read-only option "stream_lo_bits" = 8 / 16); 0: as fp32 throughout
  *   "qkv_attn"        [HG_QKV_ATTN]        1: in the LayerNorm-folded blocks of the vision tower in_proj and attention run as ONE kernel
  *                      (hoigen_amd/csrc/hg_qkv_attn.hip: q, k, v stay in LDS; 192 < tokens <= 208, i.e. ViT-B/16); 0: two kernels with the
  *                      qkv matrix in HBM between them; 2: the one kernel wherever the shapes allow (1 also asks that the last round
@@ -289,7 +290,7 @@ int hg_test_gemm_ln(hg_ctx*, const float* a, const float* w, const float* bias, 
                     int kernel, const float* cs, const float* mr, const float* mu, const float* scale, float* out2,
                     float* mr_out, float* mu_out, void* stream);
 /* Test hook for the residual stream held as centre + hi + lo: `steps` (2..16) residual updates
- * x += a W^T + bias in a row through gemm_ring2 + finalize_stats, the stream between them as two fp16 halves (hilo = 1: the
+ * x += a W^T + bias in a row through gemm_ring2 + finalize_stats, the stream between them as centre + hi + lo (hilo = 1: the
  * first update reads fp32 x, the last writes fp32 x) or as fp32 throughout (hilo = 0).  x [M,N] and mu [M] (centre of the
  * first copy in, last mean out) are read-modify-written; out2 = the last centred copy (fp32), mr_out [M][2]; both may be NULL. */
 int hg_test_gemm_hilo(hg_ctx*, const float* a, const float* w, const float* bias, float* x, int M, int N, int K, int steps,
