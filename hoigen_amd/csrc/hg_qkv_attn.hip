@@ -243,7 +243,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnArgs p, c
                         v_addr[dt] = (unsigned)(size_t)(HG_LDS const char*)(Vs + key0 * ROWB + ((chunk ^ swz_v(key0)) << 4) + (vp & 1) * 8);
                     }
                 }
-                const float cexp = 0.125f * 1.4426950408889634f;   // head_dim^-0.5 * log2(e)
+                float cexp = 0.125f * 1.4426950408889634f;         // head_dim^-0.5 * log2(e)
+                asm volatile("" : "+v"(cexp));                     // (made here, per call: not a value to keep across the K loop)
                 float m = -1.0e30f, lsum = 0.f;
                 f32x16 o[2];
 #pragma unroll
@@ -363,7 +364,11 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnArgs p, c
                     lsum += ps;
                 }
                 if (wave >= 4) __builtin_amdgcn_s_setprio(0);
-                lsum += __shfl_xor(lsum, 32, 64);
+                {      // + the other half's partial sum (lane ^ 32): each lane's pair is (own, other) in one order or the other
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, lsum), __builtin_bit_cast(unsigned, lsum),
+                                                                     false, false);
+                    lsum = __builtin_bit_cast(float, (unsigned)sw[0]) + __builtin_bit_cast(float, (unsigned)sw[1]);
+                }
                 const float inv = 1.0f / lsum;
                 // the wave's tile leaves through its own Q rows (only this wave read them, into qf) as whole 128-byte lines
                 char* ot = smem + QA_ATT + wave * 4096;
@@ -380,12 +385,13 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnArgs p, c
                 }
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 const int cr = lane >> 3, cc = lane & 7;
+                half_t* const obase = p.out + (size_t)seq * L * p.ldo + head * HD;      // (uniform base + 32-bit lane offset)
 #pragma unroll
                 for (int rb8 = 0; rb8 < 32; rb8 += 8) {
                     const int row = rb8 + cr, qrow = qt * 32 + row;
                     if (qrow < L) {
                         const half8 v = *reinterpret_cast<const half8*>(ot + row * 128 + ((cc ^ (row & 7)) << 4));
-                        *reinterpret_cast<half8*>(p.out + ((size_t)seq * L + qrow) * p.ldo + head * HD + cc * 8) = v;
+                        *reinterpret_cast<half8*>(obase + (unsigned)(qrow * p.ldo + cc * 8)) = v;
                     }
                 }
             };
