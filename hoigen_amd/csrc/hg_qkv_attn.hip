@@ -194,19 +194,19 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnArgs p, c
             }
             // this wave's 3 column blocks -> rows of Q, K or V: block l12 = 3 (wave % 4) + c of the head = matrix l12 / 4,
             // columns 16 (l12 % 4) + 4 q ..; 16-byte chunks XOR-swizzled by row as attention_kernel's DMA leaves them
+            // (both swizzles have period 16 in the row: one address per column block, the 13 row blocks are immediate offsets)
             auto write_head = [&]() {
+                static_assert(QA_RB * 16 * ROWB < 65536, "ds_write offset field");
+                const int swk = swz_k(r16), swv = swz_v(r16);
 #pragma unroll
                 for (int c = 0; c < NCB; ++c) {
                     const int l12 = (wave & 3) * NCB + c;
                     const int mtx = l12 >> 2, sub = l12 & 3;
-                    char* base = smem + QA_ATT + mtx * QA_ASTG + (q & 1) * 8;
                     const int chunk = 2 * sub + (q >> 1);
+                    char* dst = smem + QA_ATT + mtx * QA_ASTG + (q & 1) * 8 + r16 * ROWB + ((chunk ^ (mtx == 2 ? swv : swk)) << 4);
 #pragma unroll
-                    for (int rb = 0; rb < RB; ++rb) {
-                        const int row = rb * 16 + r16;
-                        const int sw = mtx == 2 ? swz_v(row) : swz_k(row);
-                        *reinterpret_cast<u32x2*>(base + row * ROWB + ((chunk ^ sw) << 4)) = u32x2{held[rb][c][0], held[rb][c][1]};
-                    }
+                    for (int rb = 0; rb < RB; ++rb)
+                        *reinterpret_cast<u32x2*>(dst + rb * 16 * ROWB) = u32x2{held[rb][c][0], held[rb][c][1]};
                 }
             };
             // One head: wave w < 7 runs query tile w over the 7 key tiles, then stores its 32 x 64 tile.  The arithmetic per key
