@@ -513,10 +513,17 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                         for (int g2 = 0; g2 < 2; ++g2) {
                             const int n = n0 + hb * 128 + wn * 32 + g2 * 16 + 4 * q;
                             f32x4 xin;
-                            if constexpr (IN_HL) {
+                            if constexpr (IN_HL) {      // (centre + hi) + lo, two elements per instruction
+                                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                                const f32x2 mc2 = {mucv[ha][f], mucv[ha][f]};
 #pragma unroll
-                                for (int e = 0; e < 4; ++e)
-                                    xin[e] = (mucv[ha][f] + (float)hin[f][hb][g2][e]) + lin[f][hb][g2][e];
+                                for (int e2 = 0; e2 < 2; ++e2) {
+                                    const half2v h2 = {hin[f][hb][g2][2 * e2], hin[f][hb][g2][2 * e2 + 1]};
+                                    const f32x2 x2 = (mc2 + __builtin_convertvector(h2, f32x2)) +
+                                                     f32x2{lin[f][hb][g2][2 * e2], lin[f][hb][g2][2 * e2 + 1]};
+                                    xin[2 * e2] = x2[0];
+                                    xin[2 * e2 + 1] = x2[1];
+                                }
                             } else {
                                 xin = xres[ha][hb][f][g2];
                             }
@@ -526,14 +533,26 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                                 if (INTERIOR || m < p.M)
                                     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v[hb][g2];
                             }
+                            // (two elements per instruction: v_pk_add_f32, v_cvt_pk_f16_f32 - RNE like the scalar conversion; the copy is
+                            // converted once and read back from its packed form)
+                            typedef float f32x2 __attribute__((ext_vector_type(2)));
+                            const f32x2 mu2 = {muv[ha][f], muv[ha][f]};
                             float rem[4];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float d = v[hb][g2][e] - muv[ha][f];
-                                const half_t hh = (half_t)d;
-                                h16[f][hb][g2][e] = hh;
-                                rem[e] = d - (float)hh;
-                                if constexpr (OUT_HL && !HG_LO8) l16[f][hb][g2][e] = (half_t)rem[e];
+                            for (int e2 = 0; e2 < 2; ++e2) {
+                                const f32x2 d = f32x2{v[hb][g2][2 * e2], v[hb][g2][2 * e2 + 1]} - mu2;
+                                const half2v hh = __builtin_convertvector(d, half2v);
+                                h16[f][hb][g2][2 * e2] = hh[0];
+                                h16[f][hb][g2][2 * e2 + 1] = hh[1];
+                                if constexpr (OUT_HL) {
+                                    const f32x2 r = d - __builtin_convertvector(hh, f32x2);
+                                    rem[2 * e2] = r[0];
+                                    rem[2 * e2 + 1] = r[1];
+                                    if constexpr (!HG_LO8) {
+                                        l16[f][hb][g2][2 * e2] = (half_t)r[0];
+                                        l16[f][hb][g2][2 * e2 + 1] = (half_t)r[1];
+                                    }
+                                }
                             }
                             if constexpr (OUT_HL && HG_LO8) {
                                 int w8 = __builtin_amdgcn_cvt_pk_bf8_f32(rem[0], rem[1], 0, false);
@@ -549,9 +568,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
 #pragma unroll
                         for (int g2 = 0; g2 < 2; ++g2)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float d = v[hb][g2][e] - gm;
-                                m2 = fmaf(d, d, m2);
+                            for (int e2 = 0; e2 < 2; ++e2) {      // (subtraction in pairs; the sum keeps its order)
+                                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                                const f32x2 d = f32x2{v[hb][g2][2 * e2], v[hb][g2][2 * e2 + 1]} - f32x2{gm, gm};
+                                m2 = fmaf(d[0], d[0], m2);
+                                m2 = fmaf(d[1], d[1], m2);
                             }
                     m2 = sum_rows(m2);
                     if (q == 0 && (INTERIOR || m < p.M)) {
