@@ -233,7 +233,7 @@ def test_duo_short_k(ctx, M, N, K, epi):
 
 
 @pytest.mark.parametrize("M,N,K", [(197 * 12 + 5, 768, 768), (128 * 41, 768, 3072), (256 * 33 + 100, 768, 256), (128 * 394, 768, 768)])
-def test_residual_stream_as_two_fp16_halves(ctx, M, N, K):
+def test_residual_stream_as_centre_hi_lo(ctx, M, N, K):
     """GemmArgs::hl (DESIGN.md 4): five residual updates in a row with the stream held as centre + hi + lo between them (the first
     reads fp32, the last writes fp32) against the same five updates on an fp32 stream: the final rows agree to what the halves
     carry (fp16 + fp16: 22 bits of x - centre; fp16 + bf8, the default build: 13-14 bits), the last copy and statistics agree,

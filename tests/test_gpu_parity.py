@@ -578,7 +578,7 @@ def test_eval_modules_work_with_grad_mode_on(fullA, g0):
         assert torch.isfinite(Gn(mean)).all()
 
 
-def test_residual_stream_as_two_fp16_halves_matches_fp32_stream(fullA):
+def test_residual_stream_as_centre_hi_lo_matches_fp32_stream(fullA):
     """Option stream_hilo (default on): between the LayerNorm-folded blocks of variant A the residual stream
     lives as centre + hi + lo (the fp16 copy + its remainder as bf8, 13-14 bits of x - centre; two fp16 halves in an HG_LO8=0 build)
     instead of fp32.  Both arrangements sit within the parity
