@@ -301,15 +301,21 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnArgs p, c
                     if (kt + 2 < NKT && kt > 0) load_k(kt + 2, cur);
                     // ---- tile_softmax_pv(): mask, running max / rescale, P
                     f32x16& s = sc[cur];
+                    // (a tile whose keys + 16 .. + 31 lie beyond the staged rows - the last one - only has its elements r < 8: the others
+                    // are masked for every L, their exponentials are +0 and their P columns unused; leaving them out changes no bit)
+                    constexpr int NR = 16;
+                    const int nr = two_steps ? NR : NR / 2;
                     if (kt * 32 + 32 > RB * 16 - 15) {      // (tiles 0-5 lie inside every L > 192; tile 6 always needs the mask)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                            s[r] = key < L ? s[r] : -INFINITY;
+                        for (int r = 0; r < NR; ++r) {
+                            if (r < nr) {
+                                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                                s[r] = key < L ? s[r] : -INFINITY;
+                            }
                         }
                     }
-                    float mx = max3(max3(s[0], s[1], s[2]), max3(s[3], s[4], s[5]), max3(s[6], s[7], s[8]));
-                    mx = max3(mx, max3(s[9], s[10], s[11]), max3(s[12], s[13], max3(s[14], s[15], s[15])));
+                    float mx = max3(max3(s[0], s[1], s[2]), max3(s[3], s[4], s[5]), max3(s[6], s[7], s[7]));
+                    if (two_steps) mx = max3(mx, max3(s[8], s[9], s[10]), max3(max3(s[11], s[12], s[13]), s[14], s[15]));
                     {
                         const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mx), __builtin_bit_cast(unsigned, mx),
                                                                          false, false);
@@ -332,6 +338,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnArgs p, c
                     for (int g4 = 0; g4 < 4; ++g4) {
 #pragma unroll
                         for (int r = 4 * g4; r < 4 * g4 + 4; ++r) {
+                            if (r >= nr) continue;
                             const float ex = __builtin_amdgcn_exp2f(fmaf(s[r], cexp, -mc));
                             ps += ex;
                             pf[r >> 3][r & 7] = (half_t)ex;
