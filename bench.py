@@ -496,7 +496,7 @@ def run(args):
         bytes_l = sum(kernel_row(*r[:4])[2] for r in live) / max(1, len(live))
         ms_l = sum(r[4] for r in live) / max(1, len(live))
         ach = flops_l / ms_l / 1e9 if ms_l > 0 else 0.0
-        traffic = step_traffic = None
+        traffic = step_traffic = traffic_source = None
         tpath = os.path.join(HERE, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
@@ -507,8 +507,11 @@ def run(args):
                 st = tj.get("step_total_MB", {})
                 key = next((k for k in st if "(default)" in k and "stagger" in k), next((k for k in st if "(default)" in k), None))
                 step_traffic = int(st[key] * 1e6) if key else None
+                # these two are CONSTANTS read from the committed file (separate rocprofv3 --pmc passes), not counters of this run
+                traffic_source = (f"profiles/traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of round {tj.get('round', '?')}"
+                                  f" on the library at commit {tj.get('commit', 'unrecorded')}; file constants, NOT counters of this run")
             except Exception:
-                traffic = step_traffic = None
+                traffic = step_traffic = traffic_source = None
         ps = sorted(per_step)
         pct = lambda q: round(ps[min(len(ps) - 1, int(q * len(ps)))], 4)
         e2e = value / world * FLOPS_PER_CROP / 1e12
@@ -532,6 +535,7 @@ def run(args):
                                    f"{dom_launches} launches per step, shapes (M,N,K) {shapes}",
                          "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "step_traffic": step_traffic,
+                         "traffic_source": traffic_source,
                          "avg_kernel_ms": round(ms_l, 4), "avg_gflop_per_launch": round(flops_l / 1e9, 2),
                          "launches_timed": len(live),
                          "algorithmic_hbm_bytes_per_launch": int(bytes_l),

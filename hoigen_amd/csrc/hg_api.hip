@@ -946,9 +946,16 @@ int hg_set_option(hg_ctx* c, const char* key, int value) {
     else if (k == "adapter_fuse") c->opt_adapter_fuse = value != 0;
     else if (k == "adapter_fold") c->opt_adapter_fold = value != 0;
     else if (k == "stream_hilo") c->opt_stream_hilo = value != 0;
-    else if (k == "qkv_attn") { if (value >= 0 && value <= 2) c->opt_qkv_attn = value; }
-    else if (k == "qkv_attn_min_seq") { if (value >= 1) c->opt_qkv_attn_min_seq = value; }
-    else if (k == "qkv_attn_gsz") { if (value >= 0 && value <= 6) c->opt_qkv_attn_gsz = value; }
+    else if (k == "qkv_attn") {
+        if (value < 0 || value > 2) return fail(c, HG_ERR_INVALID, "qkv_attn must be 0, 1 or 2 (got %d)", value);
+        c->opt_qkv_attn = value;
+    } else if (k == "qkv_attn_min_seq") {
+        if (value < 1) return fail(c, HG_ERR_INVALID, "qkv_attn_min_seq must be >= 1 (got %d)", value);
+        c->opt_qkv_attn_min_seq = value;
+    } else if (k == "qkv_attn_gsz") {
+        if (value < 0 || value > 6) return fail(c, HG_ERR_INVALID, "qkv_attn_gsz must be 0 .. 6 (got %d)", value);
+        c->opt_qkv_attn_gsz = value;
+    }
     else return fail(c, HG_ERR_INVALID, "unknown option '%s'", key);
     return HG_OK;
 }

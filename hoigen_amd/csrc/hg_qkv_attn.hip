@@ -205,8 +205,14 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnArgs p, c
                     const int chunk = 2 * sub + (q >> 1);
                     char* dst = smem + QA_ATT + mtx * QA_ASTG + (q & 1) * 8 + r16 * ROWB + ((chunk ^ (mtx == 2 ? swv : swk)) << 4);
 #pragma unroll
-                    for (int rb = 0; rb < RB; ++rb)
-                        *reinterpret_cast<u32x2*>(dst + rb * 16 * ROWB) = u32x2{held[rb][c][0], held[rb][c][1]};
+                    for (int rb = 0; rb < RB; ++rb) {
+                        u32x2 hv = u32x2{held[rb][c][0], held[rb][c][1]};
+                        // V rows >= L are the NEXT sequence's first rows (or workspace padding): their keys are masked (P = 0), but
+                        // 0 * Inf / 0 * NaN in P V would poison every query of THIS sequence - they are stored as zeros
+                        // (attention_kernel clamps its pad rows to row L - 1 instead; with finite data both give the same bits)
+                        if (rb == RB - 1 && mtx == 2 && (RB - 1) * 16 + r16 >= p.L) hv = u32x2{0u, 0u};
+                        *reinterpret_cast<u32x2*>(dst + rb * 16 * ROWB) = hv;
+                    }
                 }
             };
             // One head: wave w < 7 runs query tile w over the 7 key tiles, then stores its 32 x 64 tile.  The arithmetic per key

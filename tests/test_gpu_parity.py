@@ -609,3 +609,37 @@ def test_residual_stream_as_centre_hi_lo_matches_fp32_stream(fullA):
     finally:
         fullA.set_option("stream_hilo", 1)
         fullA.set_option("last_block_row0", 1)
+
+
+def test_non_finite_crop_does_not_poison_its_neighbours(fullA):
+    """Rows are independent in the reference (clipnet/model.py:219-236: nothing mixes crops), also for non-finite data.  The fused
+    in_proj + attention kernel computes 208-row tiles of a 197-token sequence: the 11 pad rows of V are the NEXT crop's first rows
+    (or workspace rows an earlier, larger call left behind); their keys are masked, but 0 * NaN in P V is NaN - they are stored as
+    zeros (review of round 4).  (a) one NaN crop inside a batch leaves every other crop finite and unchanged; (b) a clean batch of 40
+    after a batch of 256 whose crop 40 was NaN is clean."""
+    d = dev()
+    torch.manual_seed(5)
+    big = torch.randn(256, 3, 224, 224, device=d)
+    clean = fullA.visual.forward_trace(big)[0]
+    bad = big.clone()
+    bad[40] = float("nan")
+    out = fullA.visual.forward_trace(bad)[0]
+    finite = torch.isfinite(out).all(dim=1)
+    assert not finite[40], "the NaN crop itself must not come out finite"
+    keep = torch.ones(256, dtype=torch.bool, device=d)
+    keep[40] = False
+    assert finite[keep].all(), f"crops {(~finite & keep).nonzero().flatten().tolist()} were poisoned by crop 40"
+    assert torch.equal(out[keep], clean[keep])
+    small = fullA.visual.forward_trace(big[:40])[0]        # the workspace rows behind row 40 * 197 still hold the NaN crop's activations
+    assert torch.isfinite(small).all()
+    assert torch.equal(small, clean[:40])
+
+
+def test_set_option_rejects_out_of_range_values(fullA):
+    """include/hoigen_amd.h: unknown keys and out-of-range values return HG_ERR_INVALID (the façade raises and does not record them)."""
+    fullA.visual.forward_trace(torch.zeros(1, 3, 224, 224, device=dev()))      # (creates the native context)
+    before = dict(fullA.visual._ctx.options)
+    for key, val in (("qkv_attn", 3), ("qkv_attn", -1), ("qkv_attn_min_seq", 0), ("qkv_attn_gsz", 7), ("no_such_option", 1)):
+        with pytest.raises(RuntimeError):
+            fullA.visual.set_option(key, val)
+    assert fullA.visual._ctx.options == before
