@@ -95,6 +95,7 @@ struct Vae {
     int dim = 0, eh = 0, gh = 0;
     half_t *e_w0 = nullptr, *e_wml = nullptr, *g_w0 = nullptr, *g_w2 = nullptr;
     float *e_b0 = nullptr, *e_bml = nullptr, *g_b0 = nullptr, *g_b2 = nullptr;
+    half_t* wp = nullptr;      // the same weights as the fragment stream of the one-kernel path (hg_vae_fused.hip): [E0 | E1 | G]
     // the same stacked mean | log_var operand with its rows interleaved in blocks of 128 (EPI_VAE_REPARAM_F32)
     std::vector<void*> owned;
 };
@@ -127,6 +128,7 @@ struct hg_ctx {
     Cache cache[HG_MAX_CACHE_SLOTS];
     // workspace (grow-only)
     Buf x, h, qkv, att, fc, head16, tok32, small, i32, ad32, ad16, adkv, mr, mu, muc, stats, pre, pretab, cx, ca, ch, cf, cq;
+    Buf zpark;           // hg_vae_fused.hip: the encoder's first z half as fp16 fragments, per wave
     Buf xlo;             // low half of the residual stream while it is held as centre + hi + lo (GemmArgs::hl)
     int max_chunk_img = 256;
     int max_chunk_txt = 640;
@@ -142,6 +144,9 @@ struct hg_ctx {
     int opt_qkv_attn_min_seq = 32;   // ... from this many sequences per call on, and where its last round of items is filled well
                                      // enough (qkv_attn_pays; qkv_attn = 2: wherever the shapes allow)
     int opt_qkv_attn_gsz = 0;    // head pairs per XCD group of that kernel (0 = all)
+    int opt_vae_fused = 1;       // CoOp-VAE Encoder -> reparameterise -> Generator as ONE kernel (hg_vae_fused.hip) for the rows that fill
+                                 // whole rounds of 128-row items over the CUs (the rest: the GEMM path); 2: every row; 0: GEMM path only
+    int n_cu = 256;
     // sticky device->host flag (host-mapped): set by clamp_eot when a caller-supplied text truncation was shorter than
     // max(EOT)+1 (a stale host memo); reported as HG_ERR_INVALID by the next text call
     int32_t* eot_flag = nullptr;
@@ -919,6 +924,8 @@ hg_ctx* hg_create(int device) {
     c->device = device;
     {
         DevGuard g(c);
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
         if (hipHostMalloc((void**)&c->eot_flag, 64, hipHostMallocMapped) == hipSuccess && c->eot_flag) *c->eot_flag = 0;
         else c->eot_flag = nullptr;
         if (hipMalloc((void**)&c->eot_flag_dev, 64) != hipSuccess) c->eot_flag_dev = nullptr;
@@ -928,7 +935,7 @@ hg_ctx* hg_create(int device) {
                                                            {"HG_LN_FUSE", "ln_fuse"}, {"HG_ADAPTER_FUSE", "adapter_fuse"},
                                                            {"HG_ADAPTER_FOLD", "adapter_fold"}, {"HG_STREAM_HILO", "stream_hilo"},
                                                            {"HG_QKV_ATTN", "qkv_attn"}, {"HG_QKV_ATTN_MIN_SEQ", "qkv_attn_min_seq"},
-                                                           {"HG_QKV_ATTN_GSZ", "qkv_attn_gsz"}};
+                                                           {"HG_QKV_ATTN_GSZ", "qkv_attn_gsz"}, {"HG_VAE_FUSED", "vae_fused"}};
     for (auto& o : init)
         if (const char* e = getenv(o.env)) (void)hg_set_option(c, o.key, atoi(e));      // (out-of-range values are ignored)
     c->err.clear();
@@ -956,6 +963,10 @@ int hg_set_option(hg_ctx* c, const char* key, int value) {
         if (value < 0 || value > 6) return fail(c, HG_ERR_INVALID, "qkv_attn_gsz must be 0 .. 6 (got %d)", value);
         c->opt_qkv_attn_gsz = value;
     }
+    else if (k == "vae_fused") {
+        if (value < 0 || value > 2) return fail(c, HG_ERR_INVALID, "vae_fused must be 0, 1 or 2 (got %d)", value);
+        c->opt_vae_fused = value;
+    }
     else return fail(c, HG_ERR_INVALID, "unknown option '%s'", key);
     return HG_OK;
 }
@@ -973,6 +984,7 @@ int hg_get_option(hg_ctx* c, const char* key, int* value) {
     else if (k == "qkv_attn") *value = c->opt_qkv_attn;
     else if (k == "qkv_attn_min_seq") *value = c->opt_qkv_attn_min_seq;
     else if (k == "qkv_attn_gsz") *value = c->opt_qkv_attn_gsz;
+    else if (k == "vae_fused") *value = c->opt_vae_fused;
     else return fail(c, HG_ERR_INVALID, "unknown option '%s'", key);
     return HG_OK;
 }
@@ -988,7 +1000,7 @@ void hg_destroy(hg_ctx* c) {
     for (auto& m : c->mlp) free_all(m.owned);
     for (auto& m : c->cache) free_all(m.owned);
     Buf* bufs[] = {&c->x, &c->h, &c->qkv, &c->att, &c->fc, &c->head16, &c->tok32, &c->small, &c->i32,
-                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq, &c->xlo};
+                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq, &c->xlo, &c->zpark};
     for (Buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
@@ -1333,7 +1345,7 @@ int hg_profile_end(hg_ctx* c, hg_prof_rec* recs, int max_recs, int32_t* n_recs) 
 int hg_workspace_bytes(hg_ctx* c, uint64_t* bytes) {
     if (!c || !bytes) return HG_ERR_INVALID;
     Buf* bufs[] = {&c->x, &c->h, &c->qkv, &c->att, &c->fc, &c->head16, &c->tok32, &c->small, &c->i32,
-                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq, &c->xlo};
+                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq, &c->xlo, &c->zpark};
     uint64_t t = 0;
     for (Buf* b : bufs) t += b->bytes;
     *bytes = t;
@@ -1465,6 +1477,15 @@ int hg_load_vae(hg_ctx* c, int slot, const hg_vae_weights* w) {
         keep_first(rc, as_f32(c, v.owned, w->gen_b2, v.dim, &v.g_b2, "Generator.net.2.bias"));
         if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
         v.gen = true;
+    }
+    // the one-kernel path's operand: the same fp16 weights as a linear stream of MFMA fragments in order of use
+    if (vae_fused_ok(v.dim, v.enc ? v.eh : 0, v.gen ? v.gh : 0)) {
+        const size_t bytes = (v.enc ? 2 * vae_fused_pass_bytes(v.eh) : 0) + (v.gen ? vae_fused_pass_bytes(v.gh) : 0);
+        void* p;
+        rc = dev_alloc(c, v.owned, bytes, &p);
+        if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
+        v.wp = (half_t*)p;
+        HG_HIP(launch_pack_vae(v.enc ? v.e_w0 : nullptr, v.e_wml, v.eh, v.gen ? v.g_w0 : nullptr, v.g_w2, v.gh, v.wp, nullptr));
     }
     HG_HIP(hipDeviceSynchronize());
     return HG_OK;
@@ -1805,6 +1826,19 @@ int hg_token_embedding(hg_ctx* c, const int32_t* ids, int n, float* out, void* s
 }
 
 // ---- CoOp-VAE ---------------------------------------------------------------------------------------------
+// Rows (from row 0) that go to the one-kernel path: its work items are 128 rows and take 0.3-0.4 ms each, so it only pays for whole
+// rounds of items over the CUs (100 000 rows = 782 items = 3 rounds of 256 + 14: the 14 would cost a fourth round); the rest - and calls
+// too small to fill most of one round - take the GEMM path, whose 256 x 256 tiles quantise a hundred times finer.
+static int vae_fused_rows(const hg_ctx* c, int R) {
+    if (c->opt_vae_fused == 0 || R <= 0) return 0;
+    if (c->opt_vae_fused == 2) return R;
+    const int per = vae_fused_rows_per_item();
+    const long items = ((long)R + per - 1) / per, ncu = c->n_cu;
+    const long full = items / ncu * ncu, rem = items - full;
+    const long take = full + (rem * 100 >= ncu * 70 ? rem : 0);
+    const long rows = take * per;
+    return (int)(rows < R ? rows : R);
+}
 static int generator_rows(hg_ctx* c, Vae& v, const half_t* z16, int R, float* bias, hipStream_t s) {
     // Generator: relu(z W0^T + b0) W2^T + b2  (main_coop_vae.py:282-296)
     half_t* g1 = (half_t*)c->fc.p;
@@ -1827,14 +1861,34 @@ int hg_vae_forward(hg_ctx* c, int slot, const float* x, const float* eps, int R,
     hipStream_t s = (hipStream_t)stream;
     HG_ON_DEVICE(c);
     const int dim = v.dim;
-    for (int r0 = 0, Rc = 0; r0 < R; r0 += Rc) {
+    // Option vae_fused = 2: the leading rows that fill whole rounds of items (all rows) go through ONE kernel, hidden layers and z on
+    // chip (hg_vae_fused.hip).  Default (1): the Encoder stays on the GEMM path - the one kernel computes its hidden layer twice (1 024
+    // output columns do not fit a wave's registers) and loses to the GEMMs there: measured 1.94 ms against 1.72 ms for 98 304 rows - and
+    // the Generator of those rows runs as the one kernel on the fp16 z the reparameterisation kernel writes (0.86 against 0.92 ms).
+    const int Rf = v.wp ? vae_fused_rows(c, R) : 0;
+    const bool all_fused = Rf > 0 && c->opt_vae_fused == 2;
+    if (all_fused) {
+        int rc = ensure(c, c->zpark, vae_fused_park_bytes(Rf));
+        if (rc) return rc;
+        VaeFusedArgs a{};
+        a.x = x; a.eps = eps; a.mean = mean; a.logvar = logvar; a.z = z; a.bias = bias; a.wp = v.wp;
+        a.b0e = v.e_b0; a.bml = v.e_bml; a.b0g = v.g_b0; a.b2g = v.g_b2; a.zpark = (half_t*)c->zpark.p;
+        a.R = Rf; a.eh = v.eh; a.gh = v.gen ? v.gh : 0; a.mode = bias ? 0 : 1; a.has_enc = true;
+        ProfScope ps(c, s, HG_PROF_VAE_FUSED, Rf, bias ? 3 : 2, v.eh);
+        HG_HIP(launch_vae_fused(a, s));
+    }
+    // rows of the call whose Generator runs as the one kernel (hybrid): the chunks below stop at that boundary
+    const int Rg = (!all_fused && bias && Rf > 0) ? Rf : 0;
+    for (int r0 = all_fused ? Rf : 0, Rc = 0; r0 < R; r0 += Rc) {
         Rc = chunk_rows(c, R - r0);
+        if (r0 < Rg && r0 + Rc > Rg) Rc = Rg - r0;
+        const bool gen_fused = r0 < Rg;
         const size_t Rp = rup(Rc, 256);
         int rc = ensure(c, c->h, Rp * dim * 2);
         if (!rc) rc = ensure(c, c->att, Rp * dim * 2);
         if (!rc) rc = ensure(c, c->qkv, Rp * v.eh * 2);
         if (!rc) rc = ensure(c, c->x, Rp * 2 * dim * 4);
-        if (!rc && bias) rc = ensure(c, c->fc, Rp * v.gh * 2);
+        if (!rc && bias && !gen_fused) rc = ensure(c, c->fc, Rp * v.gh * 2);
         if (rc) return rc;
         half_t* x16 = (half_t*)c->h.p;
         half_t* z16 = (half_t*)c->att.p;
@@ -1856,7 +1910,13 @@ int hg_vae_forward(hg_ctx* c, int slot, const float* x, const float* eps, int R,
         g.W = v.e_wml; g.bias = v.e_bml; g.n_split = dim;
         HG_HIP(gemm(c, EPI_BIAS_F32, g, s));
         HG_HIP(launch_reparam(mean_o, lv_o, eps + o, Rc, dim, z ? z + o : nullptr, z16, dim, s));
-        if (bias) {
+        if (bias && gen_fused) {
+            VaeFusedArgs a{};
+            a.x16 = z16; a.bias = bias + o; a.wp = v.wp; a.b0g = v.g_b0; a.b2g = v.g_b2;
+            a.R = Rc; a.eh = v.eh; a.gh = v.gh; a.mode = 2; a.has_enc = true;
+            ProfScope ps(c, s, HG_PROF_VAE_FUSED, Rc, 1, v.gh);
+            HG_HIP(launch_vae_fused(a, s));
+        } else if (bias) {
             rc = generator_rows(c, v, z16, Rc, bias + o, s);
             if (rc) return rc;
         }
@@ -1872,7 +1932,15 @@ int hg_generator(hg_ctx* c, int slot, const float* z, int R, float* bias, void* 
     if (R < 0 || !z || !bias) return fail(c, HG_ERR_INVALID, "bad arguments to generator");
     hipStream_t s = (hipStream_t)stream;
     HG_ON_DEVICE(c);
-    for (int r0 = 0, Rc = 0; r0 < R; r0 += Rc) {
+    const int Rf = v.wp ? vae_fused_rows(c, R) : 0;
+    if (Rf > 0) {
+        VaeFusedArgs a{};
+        a.x = z; a.bias = bias; a.wp = v.wp; a.b0g = v.g_b0; a.b2g = v.g_b2;
+        a.R = Rf; a.eh = v.enc ? v.eh : 0; a.gh = v.gh; a.mode = 2; a.has_enc = v.enc;
+        ProfScope ps(c, s, HG_PROF_VAE_FUSED, Rf, 1, v.gh);
+        HG_HIP(launch_vae_fused(a, s));
+    }
+    for (int r0 = Rf, Rc = 0; r0 < R; r0 += Rc) {
         Rc = chunk_rows(c, R - r0);
         const size_t Rp = rup(Rc, 256);
         int rc = ensure(c, c->att, Rp * v.dim * 2);

@@ -127,6 +127,35 @@ hipError_t launch_pack_qkv(const half_t* W, const float* bias, const float* cs, 
                            hipStream_t s);
 hipError_t launch_qkv_attn(const QkvAttnArgs& a, hipStream_t s);
 
+// ---- CoOp-VAE as one kernel (hg_vae_fused.hip): Encoder -> reparameterise -> Generator with both hidden layers and z on chip --------
+// (main_coop_vae.py:261-296,444-448).  wp = the weights packed by launch_pack_vae into the fragment stream the kernel walks:
+// [E0 | E1 | G] passes (encoder halves for z columns [0,256) / [256,512), generator), each vae_fused_pass_bytes(hidden) long.
+struct VaeFusedArgs {
+    const float* x = nullptr;        // [R, 512] fp32: Encoder input (mode 2: the Generator's z)
+    const half_t* x16 = nullptr;     // mode 2 only: z as fp16 [R, 512] instead of x (what the GEMM path's reparameterisation kernel writes)
+    const float* eps = nullptr;      // [R, 512] fp32 (modes 0, 1)
+    float* mean = nullptr;           // [R, 512] fp32 outputs; mean / logvar / z may be null
+    float* logvar = nullptr;
+    float* z = nullptr;
+    float* bias = nullptr;           // Generator output (modes 0, 2)
+    const half_t* wp = nullptr;
+    const float* b0e = nullptr;      // Encoder.net.0.bias [eh]
+    const float* bml = nullptr;      // mean.bias | log_var.bias [1024]
+    const float* b0g = nullptr;      // Generator.net.0.bias [gh]
+    const float* b2g = nullptr;      // Generator.net.2.bias [512]
+    half_t* zpark = nullptr;         // scratch: vae_fused_park_bytes(R) (modes 0, 1)
+    int R = 0, eh = 0, gh = 0;
+    int mode = 0;                    // 0 Encoder + Generator, 1 Encoder only, 2 Generator only
+    bool has_enc = true;             // wp starts with the two encoder passes (mode 2 skips them)
+};
+bool vae_fused_ok(int dim, int eh, int gh);          // dim == 512, hidden widths multiples of 32 up to 4096
+size_t vae_fused_pass_bytes(int hidden);
+int vae_fused_rows_per_item();                        // 128
+inline size_t vae_fused_park_bytes(int R) { return (size_t)((R + 127) / 128) * 4 * 16 * 1024; }
+hipError_t launch_pack_vae(const half_t* e_w0, const half_t* e_wml, int eh, const half_t* g_w0, const half_t* g_w2, int gh, half_t* wp,
+                           hipStream_t s);
+hipError_t launch_vae_fused(const VaeFusedArgs& a, hipStream_t s);
+
 // ---- elementwise / row kernels ---------------------------------------------------------------
 // LayerNorm over rows of fp32 x (eps 1e-5, biased variance; clipnet/model.py:153-159).
 // Input row for output row r:  gather ? r*rows_per_seq + gather[r] : r*in_row_stride_rows.

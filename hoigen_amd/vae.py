@@ -85,6 +85,19 @@ class _Slot:
         self.kind, self.idx, self.slot = state["kind"], None, None
 
 
+def set_option(key: str, value: int, device=None) -> None:
+    """Behaviour option (include/hoigen_amd.h: hg_set_option) of the native context that the VAE-family modules of ``device`` share,
+    e.g. ``vae_fused`` (Encoder -> reparameterise -> Generator as one kernel: 1 where it pays, 2 every row, 0 the GEMM path) or
+    ``chunk_rows``.  Survives re-creation of the context."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    with _Slot._lock:
+        pool = _Slot._pools.get(idx)
+        if pool is None:
+            pool = _Slot._pools[idx] = {"ctx": _Ctx(), "vae": list(range(_lib.HG_MAX_SLOTS)), "mlp": list(range(_lib.HG_MAX_SLOTS))}
+        pool["ctx"].set_option(key, value)
+
+
 class _Session:
     def __init__(self, slot: _Slot, device: torch.device):
         self.slot, self.device = slot, device

@@ -247,6 +247,11 @@ int hg_vae_loss(hg_ctx*, const float* recon, const float* x, const float* mean, 
  *                      of its (sequence, head pair) items is well filled: speed only).  Bit-identical results either way.
  *   "qkv_attn_min_seq" [HG_QKV_ATTN_MIN_SEQ] ... from this many sequences per call on (default 32)
  *   "qkv_attn_gsz"    [HG_QKV_ATTN_GSZ]    head pairs per XCD group of that kernel (0 = all six side by side; speed only)
+ *   "vae_fused"       [HG_VAE_FUSED]       1: hg_vae_forward / hg_generator run Encoder -> reparameterise -> Generator as ONE kernel
+ *                      (hoigen_amd/csrc/hg_vae_fused.hip: both hidden layers and z stay on chip; dim 512, hidden widths multiples of 32
+ *                      up to 4096) for the leading rows that fill whole rounds of its 128-row work items over the CUs, the GEMM path for
+ *                      the rest (and for calls too small to fill 70 % of one round); 2: the one kernel for every row; 0: GEMM path only.
+ *                      Same fp16 operand roundings on both paths; results differ by fp32 summation order.
  *   "chunk_rows"      [HG_CHUNK_ROWS]      rows per VAE / mlp_net / cache-logits chunk (>= 256; default 32768; the last chunk of a
  *                      call absorbs a tail of up to an eighth of it)
  * Unknown keys and out-of-range values return HG_ERR_INVALID. */
@@ -267,6 +272,7 @@ int hg_workspace_bytes(hg_ctx*, uint64_t* bytes);
 #define HG_PROF_ALL (-2)
 #define HG_PROF_ATTENTION 100 /* M = sequences, N = tokens per sequence, K = heads */
 #define HG_PROF_QKV_ATTN 101  /* fused in_proj + attention: M = sequences, N = tokens per sequence, K = heads */
+#define HG_PROF_VAE_FUSED 102 /* CoOp-VAE as one kernel: M = rows, N = passes per item (3 Encoder + Generator, 2 Encoder, 1 Generator), K = hidden width of the first pass */
 typedef struct {
     int32_t kind; /* GEMM epilogue class or HG_PROF_ATTENTION */
     int32_t M, N, K;

@@ -82,8 +82,12 @@ def test_fused_in_proj_attention_is_bit_identical_inside_encode_image(fullA):
         fullA.visual.set_option("last_block_row0", 1)
 
 def test_config4_vae_100k_rows_equals_chunks():
-    """BASELINE config 4: 100 000 rows through Encoder -> reparameterise -> Generator in one call (crosses the
-    32 768-row chunk boundary three times) == separate calls on the row ranges; ragged ranges included."""
+    """BASELINE config 4: 100 000 rows through Encoder -> reparameterise -> Generator in one call == separate calls on the row
+    ranges, ragged ranges included - on the GEMM path (option vae_fused = 0: crosses the 32 768-row chunk boundary three times) and on
+    the one-kernel path (vae_fused = 2: 782 work items of 128 rows), bit for bit each: a row's result depends on its path, never on its
+    neighbours or its position.  The default (vae_fused = 1) keeps the Encoder on the GEMM path and gives the Generator of the leading
+    98 304 rows (three whole rounds of items over 256 CUs) to the one kernel, the last 1 696 rows to the GEMMs; the paths agree to fp32
+    summation order."""
     d = dev()
     E, Gn = vae.Encoder().to(d), vae.Generator().to(d)
     E.load_state_dict(synth.to_torch(synth.encoder_state_dict(2)))
@@ -93,12 +97,34 @@ def test_config4_vae_100k_rows_equals_chunks():
     R = 100_000
     x = vae.l2_normalize(torch.randn(R, 512, device=d, generator=gen))
     eps = torch.randn(R, 512, device=d, generator=gen)
-    whole = V(x, eps)
-    assert all(t.shape == (R, 512) and torch.isfinite(t).all() for t in whole)
-    for lo, hi in ((0, 32768), (32768, 65536), (65536, 98304), (98304, R), (32000, 33111), (99999, R)):
-        part = V(x[lo:hi], eps[lo:hi])
-        for a, b, n in zip(part, whole, ("mean", "log_var", "z", "bias")):
-            assert torch.equal(a, b[lo:hi]), f"{n} rows [{lo},{hi}) differ from the single-call result"
+    names = ("mean", "log_var", "z", "bias")
+    whole = {}
+    try:
+        for mode in (0, 2):
+            vae.set_option("vae_fused", mode, d)
+            whole[mode] = V(x, eps)
+            assert all(t.shape == (R, 512) and torch.isfinite(t).all() for t in whole[mode])
+            for lo, hi in ((0, 32768), (32768, 65536), (65536, 98304), (98304, R), (32000, 33111), (99999, R)):
+                part = V(x[lo:hi], eps[lo:hi])
+                for a, b, n in zip(part, whole[mode], names):
+                    assert torch.equal(a, b[lo:hi]), f"vae_fused={mode}: {n} rows [{lo},{hi}) differ from the single-call result"
+        vae.set_option("vae_fused", 1, d)
+        auto = V(x, eps)
+        n_cu = torch.cuda.get_device_properties(d).multi_processor_count
+        items = (R + 127) // 128
+        full = items // n_cu * n_cu
+        rf = min(R, (full + (items - full if (items - full) * 100 >= n_cu * 70 else 0)) * 128)
+        for a, f, g, n in zip(auto, whole[2], whole[0], names):
+            err = float((f.double() - g.double()).norm() / g.double().norm())
+            assert err < 2e-4, f"{n}: one-kernel path vs GEMM path {err:.2e}"
+            if n != "bias":      # default dispatch: the Encoder and the reparameterisation stay on the GEMM path ...
+                assert torch.equal(a, g), f"{n}: the default dispatch moved the Encoder off the GEMM path"
+            else:                # ... the Generator of the leading whole rounds of items is the one kernel, on the GEMM path's fp16 z
+                assert torch.equal(a[rf:], g[rf:]) and rf > 0 and not torch.equal(a[:rf], g[:rf])
+                e2 = float((a[:rf].double() - g[:rf].double()).norm() / g[:rf].double().norm())
+                assert e2 < 2e-4, f"bias: one-kernel Generator vs GEMM Generator on the same z {e2:.2e}"
+    finally:
+        vae.set_option("vae_fused", 1, d)
     # generator-only sampling path (main_tip_finetune.py:779-781)
     z = torch.randn(R, 512, device=d, generator=gen)
     gw = Gn(z)
