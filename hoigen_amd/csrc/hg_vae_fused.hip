@@ -68,6 +68,8 @@ constexpr int VF_AHEAD = 4;                  // weight fragments read ahead of t
 static_assert(VF_LDS <= 160 * 1024, "LDS budget");
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // iterations of a pass over nb hidden blocks: nb + 1 (layer 1 of block t beside layer 2 of block t - 1), rounded up to even
 __host__ __device__ inline int vf_iters(int nb) { return (nb + 2) & ~1; }
@@ -102,7 +104,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = lane & 31, hh = lane >> 5;
     // (lane-derived values are recomputed where they are used - mbcnt behind an opaque zero, so that the computation cannot be hoisted:
     // kept live across the pass loop they are what the register allocator spills, and a scratch reload waits for vmcnt(0), i.e.
     // drains the DMA ring once per iteration: measured 4 750 instead of 2 100 cycles per iteration)
@@ -174,18 +175,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     half8 bf[VF_KS];         // B fragments of the wave's rows (x, then z)
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int row = 0, rowc = 0, item = 0;
-    bool valid = false;
+    int item = 0;
 
     // One pass over the hidden blocks: KIND 0 / 1 = encoder for z columns [256 KIND, 256 KIND + 256), 2 = generator.  (Instantiated
     // per kind, straight-line: a run-time kind joins the three epilogues behind one loop and the register allocator answers the
     // joins of 400 live registers with spills.)
     auto run_pass = [&](auto KIND_T, const int nb, const float* __restrict__ b0) {
         constexpr int KIND = decltype(KIND_T)::value;
-        // ---- first-layer bias of the pass -> LDS (block nb: zeros)
+        // ---- first-layer bias of the pass -> LDS (blocks nb, nb + 1: zeros - what a buffer load beyond the vector returns)
         {
-            float* tab = reinterpret_cast<float*>(smem + VF_TAB);
-            for (int i = tid; i < (nb + 2) * 32; i += 256) tab[i] = i < nb * 32 ? b0[i] : 0.f;
+            const __amdgpu_buffer_rsrc_t rsB0 = __builtin_amdgcn_make_buffer_rsrc((void*)b0, 0, (unsigned)nb * (32 * 4), 0x00020000);
+            const int t_now = wave * 64 + lane_now();
+            for (int i = t_now; i < (nb + 2) * 32; i += 256)
+                *reinterpret_cast<unsigned*>(smem + VF_TAB + i * 4) = __builtin_amdgcn_raw_buffer_load_b32(rsB0, i * 4, 0, 0);
             __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
             barrier_raw();
         }
@@ -265,67 +267,85 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             iteration(I1{});
         }
         VF_STAMP_B();
-        // ---- epilogue of the pass (the ring keeps filling; the next iteration's first fragments are in wr).  Lanes of rows beyond R
-        // compute a copy of row R - 1 and store nothing.  One base pointer per tensor, columns as immediates.
-        if constexpr (KIND == 2) {
-            float* orow = p.bias + (size_t)rowc * VF_DIM + 4 * hh;
-            const float* brow = p.b2g + 4 * hh;
+        // ---- epilogue of the pass (the ring keeps filling; the next iteration's first fragments are in wr).  Buffer instructions: the
+        // descriptors' sizes make rows beyond R read as zero and drop their stores, a tensor the caller did not ask for has size 0;
+        // per lane ONE 32-bit offset serves every tensor (64-bit pointers per tensor were what the allocator spilled here).
+        {
+            const int l_now = lane_now();
+            const unsigned rbytes = (unsigned)p.R * (VF_DIM * 4);
+            const unsigned voff = (unsigned)(item * VF_ROWS + wave * 32 + (l_now & 31)) * (VF_DIM * 4) + 16 * (l_now >> 5);
+            const unsigned boff = 16 * (l_now >> 5);
+            if constexpr (KIND == 2) {
+                const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, rbytes, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.b2g, 0, VF_DIM * 4, 0x00020000);
 #pragma unroll
-            for (int ob = 0; ob < 16; ++ob) {
+                for (int ob = 0; ob < 16; ++ob) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int col = 32 * ob + 8 * g;
-                    const f32x4 b2 = *reinterpret_cast<const f32x4*>(brow + col);
-                    const f32x4 v = f32x4{oacc[ob][4 * g], oacc[ob][4 * g + 1], oacc[ob][4 * g + 2], oacc[ob][4 * g + 3]} + b2;
-                    if (valid) *reinterpret_cast<f32x4*>(orow + col) = v;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-            half_t* park = p.zpark + ((size_t)(item * 4 + wave) * 16) * 512 + lane * 8;
-            const size_t ro = (size_t)rowc * VF_DIM + 4 * hh + 256 * KIND;
-            const float* erow = p.eps + ro;
-            const float* bmrow = p.bml + 4 * hh + 256 * KIND;
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                half8 zf[2];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int col = 32 * b + 8 * g;
-                    const f32x4 bm = *reinterpret_cast<const f32x4*>(bmrow + col);
-                    const f32x4 bl = *reinterpret_cast<const f32x4*>(bmrow + VF_DIM + col);
-                    const f32x4 e = *reinterpret_cast<const f32x4*>(erow + col);
-                    const f32x4 m4 = f32x4{oacc[b][4 * g], oacc[b][4 * g + 1], oacc[b][4 * g + 2], oacc[b][4 * g + 3]} + bm;
-                    const f32x4 l4 = f32x4{oacc[8 + b][4 * g], oacc[8 + b][4 * g + 1], oacc[8 + b][4 * g + 2], oacc[8 + b][4 * g + 3]} + bl;
-                    f32x4 z4;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) z4[i] = reparam1(m4[i], l4[i], e[i]);
-                    if (valid) {
-                        if (p.mean) *reinterpret_cast<f32x4*>(p.mean + ro + col) = m4;
-                        if (p.logvar) *reinterpret_cast<f32x4*>(p.logvar + ro + col) = l4;
-                        if (p.z) *reinterpret_cast<f32x4*>(p.z + ro + col) = z4;
+                    for (int g = 0; g < 4; ++g) {
+                        const int cb = (32 * ob + 8 * g) * 4;
+                        const f32x4 b2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, boff + cb, 0, 0));
+                        const f32x4 v = f32x4{oacc[ob][4 * g], oacc[ob][4 * g + 1], oacc[ob][4 * g + 2], oacc[ob][4 * g + 3]} + b2;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsO, voff + cb, 0, 0);
                     }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) zf[g >> 1][4 * (g & 1) + i] = (half_t)z4[i];
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                // z columns 256 KIND + 32 b ..: B fragments s = 16 KIND + 2 b + (0, 1) of the generator pass
-                if constexpr (KIND == 0) {
-                    *reinterpret_cast<half8*>(park + (2 * b) * 512) = zf[0];
-                    *reinterpret_cast<half8*>(park + (2 * b + 1) * 512) = zf[1];
-                } else {
-                    bf[16 + 2 * b] = zf[0];
-                    bf[16 + 2 * b + 1] = zf[1];
-                }
-                __builtin_amdgcn_sched_barrier(0);      // (one block at a time: the loads of all eight at once do not fit)
-            }
-            if constexpr (KIND == 1) {
-                wait_vm<0>();      // (this lane's own stores of pass E0)
+            } else {
+                const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc((void*)p.eps, 0, rbytes, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.bml, 0, 2 * VF_DIM * 4, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void*)p.mean, 0, p.mean ? rbytes : 0u, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc((void*)p.logvar, 0, p.logvar ? rbytes : 0u, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc((void*)p.z, 0, p.z ? rbytes : 0u, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rsP =
+                    __builtin_amdgcn_make_buffer_rsrc((void*)p.zpark, 0, (unsigned)p.n_items * (4 * 16 * 1024), 0x00020000);
+                const unsigned poff = (unsigned)l_now * 16;
+                const int psoff = (item * 4 + wave) * (16 * 1024);      // this wave's 16 parked fragments of the item
 #pragma unroll
-                for (int s = 0; s < 16; ++s) bf[s] = *reinterpret_cast<const half8*>(park + s * 512);
+                for (int b = 0; b < 8; ++b) {
+                    half8 zf[2];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int cb = (256 * KIND + 32 * b + 8 * g) * 4;
+                        const f32x4 bm = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, boff + cb, 0, 0));
+                        const f32x4 bl = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, boff + cb + VF_DIM * 4, 0, 0));
+                        const f32x4 e = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsE, voff + cb, 0, 0));
+                        const f32x4 m4 = f32x4{oacc[b][4 * g], oacc[b][4 * g + 1], oacc[b][4 * g + 2], oacc[b][4 * g + 3]} + bm;
+                        const f32x4 l4 = f32x4{oacc[8 + b][4 * g], oacc[8 + b][4 * g + 1], oacc[8 + b][4 * g + 2], oacc[8 + b][4 * g + 3]} + bl;
+                        f32x4 z4;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) z4[i] = reparam1(m4[i], l4[i], e[i]);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m4), rsM, voff + cb, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, l4), rsL, voff + cb, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, z4), rsZ, voff + cb, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) zf[g >> 1][4 * (g & 1) + i] = (half_t)z4[i];
+                        __builtin_amdgcn_sched_barrier(0);      // (four columns at a time: the exponentials' temporaries do not fit beside 400 live registers)
+                    }
+                    // z columns 256 KIND + 32 b ..: B fragments s = 16 KIND + 2 b + (0, 1) of the generator pass
+                    if constexpr (KIND == 0) {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zf[0]), rsP, poff + (2 * b) * 1024, psoff, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zf[1]), rsP, poff + (2 * b + 1) * 1024, psoff, 0);
+                    } else {
+                        bf[16 + 2 * b] = zf[0];
+                        bf[16 + 2 * b + 1] = zf[1];
+                    }
+                }
+                if constexpr (KIND == 1) {
+                    wait_vm<0>();      // (this lane's own stores of pass E0)
+#pragma unroll
+                    for (int s = 0; s < 16; ++s)
+                        bf[s] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rsP, poff + s * 1024, psoff, 0));
+                }
             }
         }
         // no store of this wave is outstanding when the counted waits of the ring resume
         wait_vm<0>();
+        // the first fragments of the next pass, read again (they have landed: the last boundary above was theirs): the copies the loop
+        // read ahead are dead across the epilogue - twenty registers it needs
+        {
+            const int base = half_sel * VF_ITER_BYTES + lane_now() * 16;
+#pragma unroll
+            for (int f = 0; f < VF_AHEAD; ++f) wr[f] = rd(base, f);
+        }
         VF_STAMP_E(tk_epi);
     };
     using K0 = std::integral_constant<int, 0>;
@@ -333,31 +353,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     using K2 = std::integral_constant<int, 2>;
 
     for (item = blockIdx.x; item < p.n_items; item += gridDim.x) {
-        row = item * VF_ROWS + wave * 32 + n;
-        valid = row < p.R;
-        rowc = valid ? row : p.R - 1;
-        // ---- the wave's rows as B fragments: element j of lane (n, h) in k-step s = x[row n][vf_kidx(s, h, j)]
+        // ---- the wave's rows as B fragments: element j of lane (n, h) in k-step s = x[row n][vf_kidx(s, h, j)]  (rows beyond R: zeros)
         VF_STAMP_B();
-        if (p.x16) {
-            typedef _Float16 half4t __attribute__((ext_vector_type(4)));
-            const half_t* xr = p.x16 + (size_t)rowc * VF_DIM + 4 * hh;
+        {
+            const int l_now = lane_now();
+            const unsigned r_now = (unsigned)(item * VF_ROWS + wave * 32 + (l_now & 31));
+            if (p.x16) {
+                const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x16, 0, (unsigned)p.R * (VF_DIM * 2), 0x00020000);
+                const unsigned voff = r_now * (VF_DIM * 2) + 8 * (l_now >> 5);
 #pragma unroll
-            for (int s = 0; s < VF_KS; ++s) {
-                const half4t a = *reinterpret_cast<const half4t*>(xr + 16 * s);
-                const half4t b = *reinterpret_cast<const half4t*>(xr + 16 * s + 8);
-                bf[s] = half8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-            }
-        } else {
-            const float* xr = p.x + (size_t)rowc * VF_DIM + 4 * hh;
-#pragma unroll
-            for (int s16 = 0; s16 < VF_KS; s16 += 16) {
-#pragma unroll
-                for (int s = s16; s < s16 + 16; ++s) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * s);
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(xr + 16 * s + 8);
-                    bf[s] = half8{(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
+                for (int s = 0; s < VF_KS; ++s) {
+                    const u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(rsX, voff + 32 * s, 0, 0);
+                    const u32x2 b = __builtin_amdgcn_raw_buffer_load_b64(rsX, voff + 32 * s + 16, 0, 0);
+                    bf[s] = __builtin_bit_cast(half8, u32x4{a[0], a[1], b[0], b[1]});
                 }
-                __builtin_amdgcn_sched_barrier(0);      // (thirty-two loads in flight at a time: two round trips per item)
+            } else {
+                const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)p.R * (VF_DIM * 4), 0x00020000);
+                const unsigned voff = r_now * (VF_DIM * 4) + 16 * (l_now >> 5);
+#pragma unroll
+                for (int s8 = 0; s8 < VF_KS; s8 += 8) {
+#pragma unroll
+                    for (int s = s8; s < s8 + 8; ++s) {
+                        const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, voff + 64 * s, 0, 0));
+                        const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, voff + 64 * s + 32, 0, 0));
+                        bf[s] = half8{(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
+                    }
+                    __builtin_amdgcn_sched_barrier(0);      // (sixteen loads in flight at a time)
+                }
             }
         }
         VF_STAMP_E(tk_x);
@@ -454,7 +476,7 @@ hipError_t launch_vae_fused(const VaeFusedArgs& a, hipStream_t s) {
     if (a.mode == 0) bytes = enc_bytes + gen_bytes;
     else if (a.mode == 1) bytes = enc_bytes;
     else { d.wp = a.wp + (a.has_enc ? enc_bytes / 2 : 0); bytes = gen_bytes; }
-    if (bytes >= (1ull << 31)) return hipErrorInvalidValue;
+    if (bytes >= (1ull << 31) || a.R > (1 << 20)) return hipErrorInvalidValue;      // (32-bit byte offsets into the [R, 512] fp32 tensors)
     d.stages_per_item = (int)(bytes / VF_STAGE);
     d.n_items = (a.R + VF_ROWS - 1) / VF_ROWS;
     static bool attr_set_d[HG_MAX_DEVICES] = {};
