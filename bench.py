@@ -52,7 +52,8 @@ KIND_NAMES = {0: "gemm bias->f16", 1: "gemm bias+QuickGELU->f16", 2: "gemm bias+
               8: "gemm_ring<LN-fold bias->f16>", 9: "gemm_ring<LN-fold bias+QuickGELU->f16>",
               10: "gemm_ring2<residual + x16 + row stats>", 11: "gemm adapter down_proj", 12: "gemm_duo<adapter up_proj>",
               13: "gemm_ring<VAE mean|log_var + reparameterise>", 14: "gemm_duo<adapter up_proj, fp16 copy only>",
-              100: "attention_kernel", 101: "qkv_attn_kernel<in_proj + attention, q k v in LDS>"}
+              100: "attention_kernel", 101: "qkv_attn_kernel<in_proj + attention, q k v in LDS>",
+              102: "vae_fused_kernel<Encoder/Generator as one kernel: M rows, N passes, K hidden>"}
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -286,6 +287,46 @@ def config3(model, dev, with_cpu: bool):
     return out
 
 
+def generation(model, dev):
+    """the generation loop of main_tip_finetune.py:759-824 - 100 iterations x three HICO branches (hoi / human / object,
+    600 targets each): z -> Generator -> PromptLearner -> TextEncoder -> L2 -> mlp_net = 180 000 generated features - through
+    hoigen_amd.generation.FeatureSampler on seeded synthetic branch weights; and the text tower's share of one step on its own."""
+    import torch
+    from hoigen_amd import vae
+    from hoigen_amd.generation import hico_sampler
+    g0 = json.load(open(os.path.join(HERE, "tests", "golden", "g0_tokens.json")))
+    sampler = hico_sampler(model, g0["_classnames"])
+    iters, bi = 100, 8
+    gen = torch.Generator(device=dev).manual_seed(5)
+    sampler.sample(iterations=2 * bi, generator=gen, batch_iters=bi)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    feat, tgt = sampler.sample(iterations=iters, generator=gen, batch_iters=bi)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    assert feat.shape == (iters * 1800, 512) and bool(torch.isfinite(feat).all())
+    # the text tower on the prompts of one step (bi iterations x 1 800 prompts), timed alone
+    prompts, toks = [], []
+    for name, br in sampler.branches.items():
+        t = br.target.to(dev).repeat(bi)
+        prompts.append(br.prompt_learner(br.generator(torch.randn(len(t), 512, device=dev, generator=gen)), t))
+        toks.append(br.prompt_learner.tokenized_prompts[t])
+    prompts, toks = torch.cat(prompts, dim=0), torch.cat(toks, dim=0)
+    Lt = int(toks.argmax(-1).max()) + 1
+    ms_text = timed(lambda: sampler.text_encoder(prompts, toks), 5)
+    executed = prompts.shape[0] * text_flops(Lt, last_block_one_row=True)
+    nominal = prompts.shape[0] * text_flops(77)
+    return {"workload": "generation loop of main_tip_finetune.py:759-824: 100 iterations x (hoi, human, object) x 600 targets -> 180 000 "
+                        "features [z -> Generator -> PromptLearner -> TextEncoder -> L2 -> mlp_net], seeded synthetic branch weights, "
+                        f"{bi} iterations per pass through the kernels",
+            "iterations": iters, "features": int(feat.shape[0]), "total_ms": round(dt * 1e3, 2),
+            "ms_per_iteration": round(dt / iters * 1e3, 4), "features_per_s": round(feat.shape[0] / dt, 0),
+            "text_tower": {"prompts": int(prompts.shape[0]), "tokens_run": Lt, "ms": round(ms_text, 4),
+                           "executed_tflops": round(executed / ms_text / 1e9, 2),
+                           "frac_executed": round(executed / ms_text / 1e9 / MFMA_PEAK_TFLOPS, 4),
+                           "nominal_tflops_at_77_tokens": round(nominal / ms_text / 1e9, 2)}}
+
+
 def config4(dev, with_cpu: bool):
     """BASELINE config 4: CoOp-VAE (Encoder -> reparameterise -> Generator) on 100 000 rows x 512."""
     import torch
@@ -302,6 +343,14 @@ def config4(dev, with_cpu: bool):
     z = torch.randn(R, 512, device=dev, generator=gen)
     ms_full = timed(lambda: V(x, eps), 10)
     ms_gen = timed(lambda: G(z), 10)
+    # the three dispatches of option vae_fused (default 1: Encoder on the GEMM path, Generator of the whole rounds of items as ONE kernel)
+    modes = {}
+    try:
+        for m_, nm in ((0, "gemm_path"), (2, "one_kernel_every_row")):
+            vae.set_option("vae_fused", m_, dev)
+            modes[nm] = {"ms": round(timed(lambda: V(x, eps), 10), 4), "generator_only_ms": round(timed(lambda: G(z), 10), 4)}
+    finally:
+        vae.set_option("vae_fused", 1, dev)
     _, recs = _lib.profile(V._slot.get(dev)[1], _lib.HG_PROF_ALL, 64, lambda: V(x, eps))
     out = {"workload": f"CoOp-VAE Encoder->reparameterise->Generator, {R} rows x 512 (BASELINE.json configs[3]); "
                        "inputs and the four outputs (mean, log_var, z, bias) fp32 in HBM",
@@ -310,6 +359,7 @@ def config4(dev, with_cpu: bool):
            "frac": round(R * 14.680e6 / ms_full / 1e9 / MFMA_PEAK_TFLOPS, 4),
            "generator_only": {"ms": round(ms_gen, 4), "tflops": round(R * 8.389e6 / ms_gen / 1e9, 2),
                               "frac": round(R * 8.389e6 / ms_gen / 1e9 / MFMA_PEAK_TFLOPS, 4)},
+           "vae_fused_option": {"default_1": {"ms": round(ms_full, 4), "generator_only_ms": round(ms_gen, 4)}, **modes},
            "launches_per_call": len(recs),
            "kernels": [{"kind": KIND_NAMES.get(k, str(k)), "M": m, "N": n, "K": kk, "ms": round(t, 4)}
                        for k, m, n, kk, t in recs]}
@@ -572,6 +622,7 @@ def run(args):
                 line["variant_c"] = variant_c(dev, crops, ms_per_step)      # (its own model; variant C always runs every row)
                 line["config3"] = config3(model, dev, with_cpu)
                 line["config4"] = config4(dev, with_cpu)
+                line["generation"] = generation(model, dev)
         print(json.dumps(line), flush=True)
     if world > 1 or force_comm:
         dist.barrier()

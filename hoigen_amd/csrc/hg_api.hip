@@ -1735,6 +1735,15 @@ static int text_check_flag(hg_ctx* c) {
     return HG_OK;
 }
 
+// Prompts per pass of the text tower: a budget of ROWS (max_chunk_txt prompts of the full context length, 640 x 77 = 49 280), so that
+// a call truncated to the 13-16 tokens its prompts really have (the generation pipeline: main_tip_finetune.py:759-824) fills the
+// GEMMs' row tiles like a full-length one does - 640 prompts of 13 tokens are 33 row tiles of 256 on 256 CUs.
+static int text_chunk_prompts(const hg_ctx* c, int Leff) {
+    const long rows = (long)c->max_chunk_txt * c->text.ctx;
+    const long n = rows / (Leff > 0 ? Leff : 1);
+    return (int)(n < 1 ? 1 : n);
+}
+
 static int text_tail(hg_ctx* c, int Tc, int Leff, const int32_t* eot, float* out, hipStream_t s) {
     Text& t = c->text;
     const int D = t.D, E = t.E;
@@ -1765,8 +1774,9 @@ int hg_encode_text_ids(hg_ctx* c, const int32_t* ids, int T, int L, float* out, 
     if (int frc = text_check_flag(c)) return frc;
     const int Leff = (trunc > 0 && trunc < L) ? trunc : L;
     if (Leff < L && c->eot_flag_dev) HG_HIP(hipMemsetAsync(c->eot_flag_dev, 0, 4, s));
-    for (int t0 = 0; t0 < T; t0 += c->max_chunk_txt) {
-        const int Tc = (T - t0 < c->max_chunk_txt) ? T - t0 : c->max_chunk_txt;
+    const int chunk = text_chunk_prompts(c, Leff);
+    for (int t0 = 0; t0 < T; t0 += chunk) {
+        const int Tc = (T - t0 < chunk) ? T - t0 : chunk;
         int rc = ensure_tower_ws(c, Tc * Leff, t.D);
         if (!rc) rc = ensure(c, c->head16, rup(Tc, 256) * t.D * 2);
         if (!rc) rc = ensure(c, c->i32, (size_t)(Tc + 4) * 4);
@@ -1796,8 +1806,9 @@ int hg_encode_text_embeds(hg_ctx* c, const float* prompts, const int32_t* eot_id
     if (int frc = text_check_flag(c)) return frc;
     const int Leff = (trunc > 0 && trunc < L) ? trunc : L;
     if (Leff < L && c->eot_flag_dev) HG_HIP(hipMemsetAsync(c->eot_flag_dev, 0, 4, s));
-    for (int r0 = 0; r0 < R; r0 += c->max_chunk_txt) {
-        const int Rc = (R - r0 < c->max_chunk_txt) ? R - r0 : c->max_chunk_txt;
+    const int chunk = text_chunk_prompts(c, Leff);
+    for (int r0 = 0; r0 < R; r0 += chunk) {
+        const int Rc = (R - r0 < chunk) ? R - r0 : chunk;
         int rc = ensure_tower_ws(c, Rc * Leff, t.D);
         if (!rc) rc = ensure(c, c->head16, rup(Rc, 256) * t.D * 2);
         if (rc) return rc;

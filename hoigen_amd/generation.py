@@ -61,17 +61,65 @@ class FeatureSampler:
         return out
 
     @torch.no_grad()
-    def sample(self, iterations: int = 100, generator: Optional[torch.Generator] = None
+    def sample(self, iterations: int = 100, generator: Optional[torch.Generator] = None, batch_iters: int = 4
                ) -> Tuple[torch.Tensor, torch.Tensor]:
         """-> (gen_feature [iterations * sum(n), 512], gen_target) in the reference's concatenation order:
-        all iterations of the first branch, then the second, ... (main_tip_finetune.py:817-824)."""
+        all iterations of the first branch, then the second, ... (main_tip_finetune.py:817-824).
+
+        ``batch_iters`` iterations go through the kernels as ONE step (the iterations are independent draws: their rows are stacked,
+        iteration-major, per branch): one iteration's 1 800 prompts at 13-16 executed tokens are 113 row tiles of 256 on 256 CUs - less
+        than half a round per GEMM; the latents are drawn per iteration and branch in the reference's order either way."""
         dev = self.clip.positional_embedding.device
         feats: "Dict[str, List[torch.Tensor]]" = {k: [] for k in self.branches}
-        for _ in range(iterations):
-            z = {k: torch.randn(len(b.target), b.generator.dim, device=dev, generator=generator)
-                 for k, b in self.branches.items()}
-            for k, v in self.step(z).items():
-                feats[k].append(v)
+        saved = {k: b.target for k, b in self.branches.items()}
+        done = 0
+        try:
+            while done < iterations:
+                k_it = min(max(1, batch_iters), iterations - done)
+                zs = [{k: torch.randn(len(saved[k]), b.generator.dim, device=dev, generator=generator) for k, b in self.branches.items()}
+                      for _ in range(k_it)]
+                for k, b in self.branches.items():
+                    b.target = saved[k].repeat(k_it)
+                z = {k: torch.cat([zi[k] for zi in zs], dim=0) for k in self.branches}
+                for k, v in self.step(z).items():
+                    feats[k].append(v)
+                done += k_it
+        finally:
+            for k, b in self.branches.items():
+                b.target = saved[k]
         gen_feature = torch.cat([torch.cat(feats[k], dim=0) for k in self.branches], dim=0)
         gen_target = torch.cat([b.target.to(dev).repeat(iterations) for b in self.branches.values()], dim=0)
         return gen_feature, gen_target
+
+
+def hico_sampler(clip_model: CLIP, classnames: "Dict[str, Sequence[str]]", seed: int = 70) -> FeatureSampler:
+    """The three-branch sampler of main_tip_finetune.py:693-824 on seeded synthetic Generator / mlp_net / context weights (the
+    reference loads ./ckpt/<zs_type>/*_50.pth, not reachable offline): hoi = 600 HOI names, targets arange(600); human and object =
+    the 80 human / object names, both with target HOI_IDX_TO_OBJ_IDX[i] as the reference has it (:772-779) - here the object index of
+    the HOI's name.  ``classnames``: {"hoi": [...600], "hum": [...80], "obj": [...80]} (tests/golden/g0_tokens.json "_classnames")."""
+    from . import synth
+    dev = clip_model.positional_embedding.device
+    m = clip_model
+    hoi_names, obj_names = list(classnames["hoi"]), list(classnames["obj"])
+    # object index of every HOI: the object is the tail of the HOI name ("ride bicycle" -> "bicycle"); longest match wins
+    by_len = sorted(range(len(obj_names)), key=lambda i: -len(obj_names[i]))
+    def obj_of(name):
+        nm = name.replace("_", " ")
+        for i in by_len:
+            if nm.endswith(obj_names[i].replace("_", " ")):
+                return i
+        return 0
+    hoi_to_obj = torch.tensor([obj_of(n) for n in hoi_names])
+    spec = (("hoi", vae.PromptLearner_hoi, hoi_names, torch.arange(len(hoi_names))),
+            ("human", vae.PromptLearner_h, list(classnames["hum"]), hoi_to_obj),
+            ("object", vae.PromptLearner_o, obj_names, hoi_to_obj))
+    branches = {}
+    for i, (k, cls, names, tgt) in enumerate(spec):
+        G_, M_ = vae.Generator().to(dev), vae.mlp_net(512, 512, 512).to(dev)
+        G_.load_state_dict(synth.to_torch(synth.generator_state_dict(seed + i)))
+        M_.load_state_dict(synth.to_torch(synth.mlp_net_state_dict(seed + 10 + i)))
+        pl = cls(names, m).to(dev)
+        with torch.no_grad():
+            pl.ctx.copy_(torch.from_numpy(synth.hg_normal((pl.n_ctx, 512), seed + 20 + i, 0.02)).to(pl.ctx.dtype))
+        branches[k] = Branch(G_, pl, M_, tgt)
+    return FeatureSampler(m, branches)

@@ -11,6 +11,11 @@ G.load_state_dict(synth.to_torch(synth.generator_state_dict(3)))
 R = int(os.environ.get("R", 100000))
 x = torch.nn.functional.normalize(torch.randn(R, 512, device=dev), dim=-1)
 eps = torch.randn(R, 512, device=dev)
+if os.environ.get("ZERO"):      # all-zero operands: what the same instruction stream takes when the MFMA datapath does not toggle (power / clock)
+    for m in (E, G):
+        for prm in m.parameters():
+            prm.data.zero_()
+    x.zero_(); eps.zero_()
 V = vae.VAE(E, G)
 for _ in range(3):
     V(x, eps)
