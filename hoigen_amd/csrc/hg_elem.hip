@@ -503,7 +503,7 @@ __global__ void copy_rows_hilo_kernel(const half_t* __restrict__ hi, const half_
     float lof;
     if constexpr (HG_LO8) {      // bf8 (e5m2) = the top byte of an fp16
         const unsigned short b = reinterpret_cast<const unsigned char*>(lo)[lo_i];
-        lof = (float)__builtin_bit_cast(half_t, (unsigned short)(b << 8));
+        lof = (float)__builtin_bit_cast(half_t, (unsigned short)(b << 8)) * (1.0f / HG_LO_SCALE);
     } else {
         lof = (float)lo[lo_i];
     }

@@ -519,8 +519,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
 #pragma unroll
                                 for (int e2 = 0; e2 < 2; ++e2) {
                                     const half2v h2 = {hin[f][hb][g2][2 * e2], hin[f][hb][g2][2 * e2 + 1]};
-                                    const f32x2 x2 = (mc2 + __builtin_convertvector(h2, f32x2)) +
-                                                     f32x2{lin[f][hb][g2][2 * e2], lin[f][hb][g2][2 * e2 + 1]};
+                                    // (lo is stored scaled by HG_LO_SCALE when it is bf8: one packed fma instead of the add)
+                                    const f32x2 ls2 = {HG_LO8 ? 1.0f / HG_LO_SCALE : 1.0f, HG_LO8 ? 1.0f / HG_LO_SCALE : 1.0f};
+                                    const f32x2 x2 = f32x2{lin[f][hb][g2][2 * e2], lin[f][hb][g2][2 * e2 + 1]} * ls2 +
+                                                     (mc2 + __builtin_convertvector(h2, f32x2));
                                     xin[2 * e2] = x2[0];
                                     xin[2 * e2 + 1] = x2[1];
                                 }
@@ -546,8 +548,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                                 h16[f][hb][g2][2 * e2 + 1] = hh[1];
                                 if constexpr (OUT_HL) {
                                     const f32x2 r = d - __builtin_convertvector(hh, f32x2);
-                                    rem[2 * e2] = r[0];
-                                    rem[2 * e2 + 1] = r[1];
+                                    const f32x2 rs = HG_LO8 ? r * f32x2{HG_LO_SCALE, HG_LO_SCALE} : r;
+                                    rem[2 * e2] = rs[0];
+                                    rem[2 * e2 + 1] = rs[1];
                                     if constexpr (!HG_LO8) {
                                         l16[f][hb][g2][2 * e2] = (half_t)r[0];
                                         l16[f][hb][g2][2 * e2 + 1] = (half_t)r[1];

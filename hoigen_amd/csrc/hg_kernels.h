@@ -39,6 +39,13 @@ enum Epilogue : int {
 #ifndef HG_LO8
 #define HG_LO8 1
 #endif
+// The bf8 low half holds the remainder TIMES 2^10: the remainder of an fp16 rounding is <= 2^-11 of the element, so unscaled it sits
+// 11 binades below hi and - e5m2 has fp16's exponent range - flushes to zero once the element is below ~0.25 (a stream whose rows
+// spread by 0.02 would travel as fp16 alone); scaled it is normal wherever |x - centre| >= 2.4e-4 (hi: 6.1e-5) and cannot overflow
+// (<= half of |hi|).  One packed multiply on the way out, the add on the way in becomes a packed fma.
+#ifndef HG_LO_SCALE
+#define HG_LO_SCALE 1024.0f
+#endif
 
 struct GemmArgs {
     const half_t* A;   // [M, lda] (K contiguous)

@@ -643,3 +643,29 @@ def test_set_option_rejects_out_of_range_values(fullA):
         with pytest.raises(RuntimeError):
             fullA.visual.set_option(key, val)
     assert fullA.visual._ctx.options == before
+
+
+def test_small_scale_residual_stream_vs_oracle():
+    """The hi / lo residual stream holds x as centre + fp16 + bf8 with NO per-row scale: a stream whose rows spread by 0.02 (here:
+    ln_pre.weight x 0.02 and small block outputs) puts the fp16 remainder at ~1e-5 - below e5m2's normal range unless the low half is
+    stored scaled (HG_LO_SCALE, hg_kernels.h).  40 crops (the fused in_proj + attention kernel and the hi / lo stream both engage)
+    against the oracle, both stream arrangements, every row of the last block."""
+    from oracle import clip_oracle as co
+    raw = synth.clip_state_dict(synth.VIT_B16, 0)
+    raw["visual.ln_pre.weight"] = (raw["visual.ln_pre.weight"] * 0.02).astype(np.float32)
+    raw["visual.ln_pre.bias"] = (raw["visual.ln_pre.bias"] * 0.02).astype(np.float32)
+    for i in range(12):      # keep the block updates at the stream's scale: otherwise the first residual add restores a spread of ~1
+        for k in ("attn.out_proj", "mlp.c_proj"):
+            raw[f"visual.transformer.resblocks.{i}.{k}.weight"] = (raw[f"visual.transformer.resblocks.{i}.{k}.weight"] * 0.02).astype(np.float32)
+            raw[f"visual.transformer.resblocks.{i}.{k}.bias"] = (raw[f"visual.transformer.resblocks.{i}.{k}.bias"] * 0.02).astype(np.float32)
+    sd = co.reference_weight_rounding(raw)
+    img = torch.from_numpy(synth.crops(40, 224, seed=79))
+    ref = co.encode_image(sd, img[:6]).numpy()
+    m = build_model(synth.to_torch(raw)).to(dev())
+    m.visual.forward_trace(img[:1].to(dev()))
+    m.set_option("last_block_row0", 0)
+    for mode in (1, 0):
+        m.set_option("stream_hilo", mode)
+        out = m.visual.forward_trace(img.to(dev()))[0]
+        e = check(out[:6], ref, what=f"small-scale stream, stream_hilo={mode}")
+        print(f"\nsmall-scale residual stream rel-L2 vs oracle, stream_hilo={mode}: {e:.3e}")
