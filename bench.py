@@ -296,7 +296,7 @@ def generation(model, dev):
     from hoigen_amd.generation import hico_sampler
     g0 = json.load(open(os.path.join(HERE, "tests", "golden", "g0_tokens.json")))
     sampler = hico_sampler(model, g0["_classnames"])
-    iters, bi = 100, 8
+    iters, bi = 100, sampler._auto_batch(100)
     gen = torch.Generator(device=dev).manual_seed(5)
     sampler.sample(iterations=2 * bi, generator=gen, batch_iters=bi)
     torch.cuda.synchronize(dev)

@@ -131,7 +131,7 @@ struct hg_ctx {
     Buf zpark;           // hg_vae_fused.hip: the encoder's first z half as fp16 fragments, per wave
     Buf xlo;             // low half of the residual stream while it is held as centre + hi + lo (GemmArgs::hl)
     int max_chunk_img = 256;
-    int max_chunk_txt = 640;
+    int text_rows_budget = 65536;      // rows (prompts x executed tokens) per pass of the text tower (text_chunk_prompts)
     int max_chunk_rows = 32768;
     // behaviour options: hg_set_option; the environment (HG_LAST_BLOCK_ROW0, HG_LN_FUSE, HG_ADAPTER_FUSE, HG_ADAPTER_FOLD,
     // HG_CHUNK_ROWS) only gives their values at hg_create - nothing on the call path reads the environment
@@ -1735,13 +1735,19 @@ static int text_check_flag(hg_ctx* c) {
     return HG_OK;
 }
 
-// Prompts per pass of the text tower: a budget of ROWS (max_chunk_txt prompts of the full context length, 640 x 77 = 49 280), so that
-// a call truncated to the 13-16 tokens its prompts really have (the generation pipeline: main_tip_finetune.py:759-824) fills the
-// GEMMs' row tiles like a full-length one does - 640 prompts of 13 tokens are 33 row tiles of 256 on 256 CUs.
-static int text_chunk_prompts(const hg_ctx* c, int Leff) {
-    const long rows = (long)c->max_chunk_txt * c->text.ctx;
-    const long n = rows / (Leff > 0 ? Leff : 1);
-    return (int)(n < 1 ? 1 : n);
+// Prompts per pass of the text tower: a budget of ROWS, so that a call truncated to the 13-16 tokens its prompts really have (the
+// generation pipeline: main_tip_finetune.py:759-824) fills the GEMMs' row tiles like a full-length one does - 640 prompts of 13 tokens
+// are 33 row tiles of 256 on 256 CUs.  The budget is 65 536 rows: with D = 512 every GEMM of a block then fills whole rounds (residual
+// GEMMs 512 x 2 tiles of 128 x 256 on 2 x 256 workgroups; in_proj 256 x 6 and c_fc 256 x 8 tiles of 256 x 256 on 256) - the 49 280
+// rows of 640 full-length prompts leave them at 1.50, 4.52 and 6.03 rounds.  A call longer than one pass is cut into EQUAL passes
+// (no small tail pass).  A call that fits one pass is one pass, as before (600 prompts x 77 tokens = 46 200 rows).
+static int text_chunk_prompts(const hg_ctx* c, int n_prompts, int Leff) {
+    const long budget = c->text_rows_budget, L = Leff > 0 ? Leff : 1;
+    long per = budget / L;
+    if (per < 1) per = 1;
+    if (n_prompts <= per) return n_prompts > 0 ? n_prompts : 1;
+    const long passes = (n_prompts + per - 1) / per;
+    return (int)((n_prompts + passes - 1) / passes);
 }
 
 static int text_tail(hg_ctx* c, int Tc, int Leff, const int32_t* eot, float* out, hipStream_t s) {
@@ -1774,7 +1780,7 @@ int hg_encode_text_ids(hg_ctx* c, const int32_t* ids, int T, int L, float* out, 
     if (int frc = text_check_flag(c)) return frc;
     const int Leff = (trunc > 0 && trunc < L) ? trunc : L;
     if (Leff < L && c->eot_flag_dev) HG_HIP(hipMemsetAsync(c->eot_flag_dev, 0, 4, s));
-    const int chunk = text_chunk_prompts(c, Leff);
+    const int chunk = text_chunk_prompts(c, T, Leff);
     for (int t0 = 0; t0 < T; t0 += chunk) {
         const int Tc = (T - t0 < chunk) ? T - t0 : chunk;
         int rc = ensure_tower_ws(c, Tc * Leff, t.D);
@@ -1806,7 +1812,7 @@ int hg_encode_text_embeds(hg_ctx* c, const float* prompts, const int32_t* eot_id
     if (int frc = text_check_flag(c)) return frc;
     const int Leff = (trunc > 0 && trunc < L) ? trunc : L;
     if (Leff < L && c->eot_flag_dev) HG_HIP(hipMemsetAsync(c->eot_flag_dev, 0, 4, s));
-    const int chunk = text_chunk_prompts(c, Leff);
+    const int chunk = text_chunk_prompts(c, R, Leff);
     for (int r0 = 0; r0 < R; r0 += chunk) {
         const int Rc = (R - r0 < chunk) ? R - r0 : chunk;
         int rc = ensure_tower_ws(c, Rc * Leff, t.D);
@@ -1890,6 +1896,10 @@ int hg_vae_forward(hg_ctx* c, int slot, const float* x, const float* eps, int R,
     }
     // rows of the call whose Generator runs as the one kernel (hybrid): the chunks below stop at that boundary
     const int Rg = (!all_fused && bias && Rf > 0) ? Rf : 0;
+    if (Rg > 0) {      // z of those rows as fp16, for ONE Generator launch behind the chunks (three items per CU instead of three launches)
+        int rc = ensure(c, c->zpark, (size_t)rup(Rg, 256) * dim * 2);
+        if (rc) return rc;
+    }
     for (int r0 = all_fused ? Rf : 0, Rc = 0; r0 < R; r0 += Rc) {
         Rc = chunk_rows(c, R - r0);
         if (r0 < Rg && r0 + Rc > Rg) Rc = Rg - r0;
@@ -1902,10 +1912,10 @@ int hg_vae_forward(hg_ctx* c, int slot, const float* x, const float* eps, int R,
         if (!rc && bias && !gen_fused) rc = ensure(c, c->fc, Rp * v.gh * 2);
         if (rc) return rc;
         half_t* x16 = (half_t*)c->h.p;
-        half_t* z16 = (half_t*)c->att.p;
+        const size_t o = (size_t)r0 * dim;
+        half_t* z16 = gen_fused ? (half_t*)c->zpark.p + o : (half_t*)c->att.p;
         half_t* h1 = (half_t*)c->qkv.p;
         float* ml = (float*)c->x.p;          // [2][Rp, dim] planes for the halves the caller did not ask for
-        const size_t o = (size_t)r0 * dim;
         float* mean_o = mean ? mean + o : ml;
         float* lv_o = logvar ? logvar + o : ml + Rp * dim;
         HG_HIP(launch_f32_to_f16(x + o, x16, (size_t)Rc * dim, s));
@@ -1921,16 +1931,17 @@ int hg_vae_forward(hg_ctx* c, int slot, const float* x, const float* eps, int R,
         g.W = v.e_wml; g.bias = v.e_bml; g.n_split = dim;
         HG_HIP(gemm(c, EPI_BIAS_F32, g, s));
         HG_HIP(launch_reparam(mean_o, lv_o, eps + o, Rc, dim, z ? z + o : nullptr, z16, dim, s));
-        if (bias && gen_fused) {
-            VaeFusedArgs a{};
-            a.x16 = z16; a.bias = bias + o; a.wp = v.wp; a.b0g = v.g_b0; a.b2g = v.g_b2;
-            a.R = Rc; a.eh = v.eh; a.gh = v.gh; a.mode = 2; a.has_enc = true;
-            ProfScope ps(c, s, HG_PROF_VAE_FUSED, Rc, 1, v.gh);
-            HG_HIP(launch_vae_fused(a, s));
-        } else if (bias) {
+        if (bias && !gen_fused) {
             rc = generator_rows(c, v, z16, Rc, bias + o, s);
             if (rc) return rc;
         }
+    }
+    if (Rg > 0) {
+        VaeFusedArgs a{};
+        a.x16 = (const half_t*)c->zpark.p; a.bias = bias; a.wp = v.wp; a.b0g = v.g_b0; a.b2g = v.g_b2;
+        a.R = Rg; a.eh = v.eh; a.gh = v.gh; a.mode = 2; a.has_enc = true;
+        ProfScope ps(c, s, HG_PROF_VAE_FUSED, Rg, 1, v.gh);
+        HG_HIP(launch_vae_fused(a, s));
     }
     return HG_OK;
 }

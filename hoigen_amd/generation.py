@@ -61,15 +61,34 @@ class FeatureSampler:
         return out
 
     @torch.no_grad()
-    def sample(self, iterations: int = 100, generator: Optional[torch.Generator] = None, batch_iters: int = 4
+    TEXT_PASS_ROWS = 65536      # rows (prompts x executed tokens) of one pass of the text tower (hg_api.hip: text_chunk_prompts)
+
+    def _auto_batch(self, iterations: int) -> int:
+        """Iterations per step that fill the text tower's passes best: rows of a step = k x prompts x executed tokens, cut into equal
+        passes of at most TEXT_PASS_ROWS; the fill of the passes decides (1 800 prompts at 14 tokens: k = 13 -> five passes 99.98 % full,
+        k = 8 -> four passes at 77 %)."""
+        n = sum(len(b.target) for b in self.branches.values())
+        lt = 1 + max(int(b.prompt_learner.tokenized_prompts.argmax(dim=-1).max()) for b in self.branches.values())
+        best, best_fill = 1, 0.0
+        for k in range(1, min(16, iterations) + 1):
+            rows = k * n * lt
+            passes = -(-rows // self.TEXT_PASS_ROWS)
+            fill = rows / (passes * self.TEXT_PASS_ROWS)
+            if fill > best_fill + 1e-9:
+                best, best_fill = k, fill
+        return best
+
+    def sample(self, iterations: int = 100, generator: Optional[torch.Generator] = None, batch_iters: int = 0
                ) -> Tuple[torch.Tensor, torch.Tensor]:
         """-> (gen_feature [iterations * sum(n), 512], gen_target) in the reference's concatenation order:
         all iterations of the first branch, then the second, ... (main_tip_finetune.py:817-824).
 
-        ``batch_iters`` iterations go through the kernels as ONE step (the iterations are independent draws: their rows are stacked,
+        ``batch_iters`` iterations (0 = chosen so that the text tower's passes are full) go through the kernels as ONE step (the iterations are independent draws: their rows are stacked,
         iteration-major, per branch): one iteration's 1 800 prompts at 13-16 executed tokens are 113 row tiles of 256 on 256 CUs - less
         than half a round per GEMM; the latents are drawn per iteration and branch in the reference's order either way."""
         dev = self.clip.positional_embedding.device
+        if batch_iters <= 0:
+            batch_iters = self._auto_batch(iterations)      # (0: chosen from the shapes)
         feats: "Dict[str, List[torch.Tensor]]" = {k: [] for k in self.branches}
         saved = {k: b.target for k, b in self.branches.items()}
         done = 0

@@ -161,20 +161,21 @@ def test_variant_c_600_crops_with_priors_equals_chunks():
 
 
 def test_text_700_prompts_equals_chunks(fullA, g0):
-    """encode_text across the 640-prompt chunk boundary (the 600 HOI + 81 object + 19 verb prompts)."""
-    rows = g0["hoi600"]["ids"] + g0["obj81"]["ids"] + g0["verb117"]["ids"][:19]
+    """encode_text across a pass boundary of the text tower (65 536 rows per pass, equal passes): 1 000 prompts x 77 tokens = two passes
+    of 500 (the 600 HOI + 81 object + 117 verb + 202 CoOp prompts); truncated to their 13-16 tokens they are one pass."""
+    rows = g0["hoi600"]["ids"] + g0["obj81"]["ids"] + g0["verb117"]["ids"] + g0["coop_hoi600"]["ids"][:202]
     ids = np.zeros((len(rows), 77), np.int64)
     for i, r in enumerate(rows):
         ids[i, :len(r)] = r
     ids = torch.from_numpy(ids).to(dev())
-    assert ids.shape[0] == 700
+    assert ids.shape[0] == 1000
     for trunc in (False, True):
         fullA.truncate_text = trunc
         whole = fullA.encode_text(ids)
         # truncation length = max(EOT)+1 over the CALL: give the pieces the same length by keeping the longest
         # prompt of the whole set in every piece
         longest = int(ids.argmax(dim=-1).argmax())
-        for lo, hi in ((0, 640), (640, 700), (630, 650)):
+        for lo, hi in ((0, 500), (500, 1000), (490, 510), (0, 640)):
             sel = torch.arange(lo, hi, device=ids.device)
             if trunc and not (lo <= longest < hi):
                 sel = torch.cat([sel, torch.tensor([longest], device=ids.device)])

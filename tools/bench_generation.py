@@ -13,8 +13,9 @@ g0 = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..
 model = build_model(synth.to_torch(synth.clip_state_dict(synth.VIT_B16, 0))).to(dev)
 sampler = hico_sampler(model, g0["_classnames"], seed=70)
 iters = int(os.environ.get("ITERS", 100))
-for bi in [int(x) for x in os.environ.get("BATCH_ITERS", "1,2,4,8").split(",")]:
-    sampler.sample(iterations=min(iters, 2 * bi), batch_iters=bi)
+print("auto batch_iters:", sampler._auto_batch(iters))
+for bi in [int(x) for x in os.environ.get("BATCH_ITERS", "1,4,8,0").split(",")]:
+    sampler.sample(iterations=min(iters, 2 * max(bi, 13)), batch_iters=bi)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     feat, tgt = sampler.sample(iterations=iters, batch_iters=bi)
