@@ -60,7 +60,6 @@ class FeatureSampler:
             o += n
         return out
 
-    @torch.no_grad()
     TEXT_PASS_ROWS = 65536      # rows (prompts x executed tokens) of one pass of the text tower (hg_api.hip: text_chunk_prompts)
 
     def _auto_batch(self, iterations: int) -> int:
@@ -78,6 +77,7 @@ class FeatureSampler:
                 best, best_fill = k, fill
         return best
 
+    @torch.no_grad()
     def sample(self, iterations: int = 100, generator: Optional[torch.Generator] = None, batch_iters: int = 0
                ) -> Tuple[torch.Tensor, torch.Tensor]:
         """-> (gen_feature [iterations * sum(n), 512], gen_target) in the reference's concatenation order:
