@@ -307,9 +307,10 @@ def generation(model, dev):
     assert feat.shape == (iters * 1800, 512) and bool(torch.isfinite(feat).all())
     # the text tower on the prompts of one step (bi iterations x 1 800 prompts), timed alone
     prompts, toks = [], []
+    lt = sampler._tokens_run()
     for name, br in sampler.branches.items():
         t = br.target.to(dev).repeat(bi)
-        prompts.append(br.prompt_learner(br.generator(torch.randn(len(t), 512, device=dev, generator=gen)), t))
+        prompts.append(br.prompt_learner(br.generator(torch.randn(len(t), 512, device=dev, generator=gen)), t, tokens=lt))
         toks.append(br.prompt_learner.tokenized_prompts[t])
     prompts, toks = torch.cat(prompts, dim=0), torch.cat(toks, dim=0)
     Lt = int(toks.argmax(-1).max()) + 1

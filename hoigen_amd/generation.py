@@ -41,18 +41,35 @@ class FeatureSampler:
         self.branches = branches
         self.text_encoder = vae.TextEncoder(clip_model)
 
+    def _tokens_run(self) -> int:
+        """max(EOT) + 1 over every class of every branch: the tokens the truncated text tower reads (clipnet/model.py:350 selects the
+        EOT row; causal attention: later positions cannot reach it)."""
+        key = tuple(id(b.prompt_learner.tokenized_prompts) for b in self.branches.values())
+        if getattr(self, "_lt_key", None) != key:
+            self._lt = 1 + max(int(b.prompt_learner.tokenized_prompts.argmax(dim=-1).max()) for b in self.branches.values())
+            self._lt_key = key
+        return self._lt
+
     @torch.no_grad()
     def step(self, z: "Dict[str, torch.Tensor]") -> "Dict[str, torch.Tensor]":
-        """One loop iteration for given latents ``z[name] [n_name, 512]`` -> features per branch."""
-        prompts, toks, sizes, names = [], [], [], []
-        for name, br in self.branches.items():
-            tgt = br.target.to(z[name].device)
+        """One loop iteration for given latents ``z[name] [n_name, 512]`` -> features per branch.  With a truncating text tower
+        (``clip_model.truncate_text``, the default) the prompts are assembled with the tokens it reads only, each branch straight into
+        its slice of the one batch the tower is called with."""
+        names = list(self.branches)
+        sizes = [len(self.branches[k].target) for k in names]
+        dev = z[names[0]].device
+        lt = self._tokens_run() if getattr(self.clip, "truncate_text", False) else None
+        L = lt if lt is not None else 1 + self.branches[names[0]].prompt_learner.n_ctx + self.branches[names[0]].prompt_learner.token_suffix.shape[1]
+        prompts = torch.empty(sum(sizes), L, z[names[0]].shape[1], device=dev, dtype=torch.float32)
+        toks, o = [], 0
+        for name, n in zip(names, sizes):
+            br = self.branches[name]
+            tgt = br.target.to(dev)
             bias = br.generator(z[name])
-            prompts.append(br.prompt_learner(bias, tgt))
+            br.prompt_learner(bias, tgt, out=prompts[o:o + n], tokens=lt)
             toks.append(br.prompt_learner.tokenized_prompts[tgt])
-            sizes.append(len(tgt))
-            names.append(name)
-        t = self.text_encoder(torch.cat(prompts, dim=0), torch.cat(toks, dim=0))   # one pass over the tower
+            o += n
+        t = self.text_encoder(prompts, torch.cat(toks, dim=0))   # one pass over the tower
         t = vae.l2_normalize(t)
         out, o = {}, 0
         for name, n in zip(names, sizes):
@@ -67,7 +84,7 @@ class FeatureSampler:
         passes of at most TEXT_PASS_ROWS; the fill of the passes decides (1 800 prompts at 14 tokens: k = 13 -> five passes 99.98 % full,
         k = 8 -> four passes at 77 %)."""
         n = sum(len(b.target) for b in self.branches.values())
-        lt = 1 + max(int(b.prompt_learner.tokenized_prompts.argmax(dim=-1).max()) for b in self.branches.values())
+        lt = self._tokens_run()
         best, best_fill = 1, 0.0
         for k in range(1, min(16, iterations) + 1):
             rows = k * n * lt

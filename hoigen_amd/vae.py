@@ -384,22 +384,34 @@ class _PromptLearner(nn.Module):
 
     @_inference_only
     @torch.no_grad()
-    def forward(self, bias: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
-        """main_coop_vae.py:119-128 -> prompts [R, L, D]."""
+    def forward(self, bias: torch.Tensor, target: torch.Tensor, out: Optional[torch.Tensor] = None,
+                tokens: Optional[int] = None) -> torch.Tensor:
+        """main_coop_vae.py:119-128 -> prompts [R, L, D].
+
+        Extensions for the device-resident sampling loop (hoigen_amd.generation): ``tokens`` = only the first ``tokens`` positions of
+        every prompt (what a text tower truncated to max(EOT) + 1 reads: 13-16 of 77), ``out`` = a caller-owned fp32 ``[R, L, D]``
+        buffer, e.g. a slice of the batch the tower is called with (no concatenation afterwards)."""
         _require_cuda(bias, "bias")
         h = _util_ctx.get(bias.device)
         bf = _f32(bias)
         R, D = bf.shape
         C_, Ls = self.token_suffix.shape[0], self.token_suffix.shape[1]
-        L = 1 + self.n_ctx + Ls
+        L_full = 1 + self.n_ctx + Ls
+        L = L_full if tokens is None else int(tokens)
+        if not (1 + self.n_ctx < L <= L_full):
+            raise RuntimeError(f"hoigen_amd: tokens must lie in ({1 + self.n_ctx}, {L_full}] (got {L})")
         tgt = target.to(device=bias.device, dtype=torch.int32).contiguous()
-        out = torch.empty(R, L, D, device=bias.device, dtype=torch.float32)
+        if out is None:
+            out = torch.empty(R, L, D, device=bias.device, dtype=torch.float32)
+        elif (out.shape != (R, L, D) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != bias.device):
+            raise RuntimeError(f"hoigen_amd: out must be a contiguous fp32 [{R}, {L}, {D}] tensor on {bias.device}")
         # fp32 views of the (usually fp16: clip_model.dtype) buffers.  They are kept on the object: a temporary made
         # inline (`_f32(t).data_ptr()`) is freed before the kernel is enqueued and its block can be handed to the
         # next temporary.  Rebuilt when the buffers or ctx change (get_prefix_suffix_token, load_state_dict, .to()).
-        key = _sig([self.token_prefix, self.token_suffix, self.ctx]) + (str(bias.device),)
+        key = _sig([self.token_prefix, self.token_suffix, self.ctx]) + (str(bias.device), L)
         if key != getattr(self, "_f32_key", None):
-            self._f32_ops = tuple(_f32(t).to(bias.device) for t in (self.token_prefix, self.token_suffix, self.ctx))
+            suf = self.token_suffix if L == L_full else self.token_suffix[:, :L - 1 - self.n_ctx, :]
+            self._f32_ops = tuple(_f32(t).to(bias.device).contiguous() for t in (self.token_prefix, suf, self.ctx))
             self._f32_key = key
         pre, suf, ctx = self._f32_ops
         with torch.cuda.device(bias.device):
