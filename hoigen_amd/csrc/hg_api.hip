@@ -1228,10 +1228,11 @@ int hg_test_attention(hg_ctx* c, const float* qkv, const float* q0, const int32_
     if (q0) {      // one query row per sequence (row sel[seq], or 0): out [n_seq, D]
         HG_HIP(launch_f32_to_f16(q0, (half_t*)c->cq.p, (size_t)n_seq * D, s));
         HG_HIP(launch_attention_row0((const half_t*)c->qkv.p, (const half_t*)c->cq.p, sel, (half_t*)c->att.p, n_seq, L,
-                                     heads, causal != 0, s));
+                                     heads, (causal & 1) != 0, s));
         HG_HIP(launch_f16_to_f32((const half_t*)c->att.p, out, (size_t)n_seq * D, s));
     } else {
-        HG_HIP(attention(c, (const half_t*)c->qkv.p, (half_t*)c->att.p, n_seq, L, heads, causal != 0, s));
+        // (causal bit 1: the one-workgroup-per-item launch for L <= 32 instead of four items per workgroup - same bits: tests)
+        HG_HIP(launch_attention((const half_t*)c->qkv.p, (half_t*)c->att.p, n_seq, L, heads, (causal & 1) != 0, s, 0, !(causal & 2)));
         HG_HIP(launch_f16_to_f32((const half_t*)c->att.p, out, M * D, s));
     }
     return HG_OK;

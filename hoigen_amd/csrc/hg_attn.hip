@@ -26,10 +26,15 @@ namespace hg {
 // reach the output.  Every wave helps to stage K and V, wave 0 then runs that query (all 32 lanes of the tile alias
 // it) through the same instruction sequence as the full kernel, so the row is bit-identical to the full kernel's; the
 // query comes from the dense matrix q0 [n_seq, D] and the result goes to a dense [n_seq, D] matrix.
-template <bool CAUSAL, bool ROW0>
+// PACK (L <= 32: one query tile, one wave per item): every wave of the workgroup takes its OWN (sequence, head) item with its own
+// 4 KiB (L <= 16) / 8 KiB of LDS - the generation pipeline's text tower runs 14-token prompts (4 681 x 8 items of one wave per pass
+// and layer): dispatched one workgroup per item the kernel is bound by the workgroup dispatch rate (51 us), four items per workgroup
+// it is not.  Same instruction sequence per wave: the item's bits do not depend on the packing.
+template <bool CAUSAL, bool ROW0, bool PACK = false>
 __global__ __launch_bounds__(448) void attention_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
                                                         int L, int heads, int nkt, const half_t* __restrict__ q0,
-                                                        const int32_t* __restrict__ sel, const int mode, const int ldo) {
+                                                        const int32_t* __restrict__ sel, const int mode, const int ldo,
+                                                        const int n_items) {
     // timing-experiment switches (HG_ATTN_MODE bits 1 no key loop, 2 no K/V staging, 4 no stores, 8 no Q loads; wrong results) exist
     // only in a -DHG_EXPERIMENTS build
 #ifdef HG_EXPERIMENTS
@@ -41,13 +46,19 @@ __global__ __launch_bounds__(448) void attention_kernel(const half_t* __restrict
     // K and V rows 0 .. rs-1 are staged, rs = L rounded up to 16 (the last key tile may be half present: its second
     // 16-key step is skipped in P V, its missing K rows read into the V region and are masked)
     const int rs = (L + 15) & ~15;
-    char* Ks = smem;
-    char* Vs = smem + rs * ROWB;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nwaves = blockDim.x >> 6;
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // PACK: this wave is "wave 0 of 1" of its own item (waves beyond the last item redo it and store nothing)
+    const int item_raw = PACK ? (int)blockIdx.x * (int)(blockDim.x >> 6) + wave_id : (int)blockIdx.x;
+    const bool item_ok = !PACK || item_raw < n_items;
+    const int item = item_ok ? item_raw : n_items - 1;
+    const int wave = PACK ? 0 : wave_id;
+    const int nwaves = PACK ? 1 : (int)(blockDim.x >> 6);
+    char* const smem_item = PACK ? smem + wave_id * (2 * rs * ROWB > 4096 ? 2 * rs * ROWB : 4096) : smem;
+    char* Ks = smem_item;
+    char* Vs = smem_item + rs * ROWB;
     const int D = heads * HD;
-    const int seq = blockIdx.x / heads, head = blockIdx.x - seq * heads;
+    const int seq = item / heads, head = item - seq * heads;
     const size_t ld = (size_t)3 * D;
     const half_t* base = qkv + (size_t)seq * L * ld + head * HD;
 
@@ -132,7 +143,7 @@ __global__ __launch_bounds__(448) void attention_kernel(const half_t* __restrict
         // wave's 32 x 64 tile goes through LDS (the K/V rows are dead once every wave has left the key loop; 16-byte
         // chunks XOR-swizzled by row) and leaves as whole 128-byte rows: lane -> (row = l >> 3, chunk = l & 7).
         __syncthreads();
-        char* ot = smem + wave * 4096;
+        char* ot = smem_item + wave * 4096;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -147,22 +158,24 @@ __global__ __launch_bounds__(448) void attention_kernel(const half_t* __restrict
         for (int rb = 0; rb < 32; rb += 8) {
             const int row = rb + cr, qq = qt * 32 + row;
             const half8 v = *reinterpret_cast<const half8*>(ot + row * 128 + ((cc ^ (row & 7)) << 4));
-            if (qq < L && !(xmode & 4))
+            if (qq < L && !(xmode & 4) && item_ok)
                 *reinterpret_cast<half8*>(out + ((size_t)seq * L + qq) * ldo + head * HD + cc * 8) = v;
         }
     }
 }
 
-template <bool CAUSAL, bool ROW0 = false>
+template <bool CAUSAL, bool ROW0 = false, bool PACK = false>
 static hipError_t launch_t(const half_t* qkv, half_t* out, int n_seq, int L, int heads, hipStream_t s,
                            const half_t* q0 = nullptr, const int32_t* sel = nullptr, int ldo = 0) {
     if (ldo <= 0) ldo = heads * HD;
     const int nkt = (L + 31) / 32;
-    const int lds = 2 * ((L + 15) & ~15) * ROWB;
+    const int lds_item = 2 * ((L + 15) & ~15) * ROWB;
+    constexpr int G = 4;                              // PACK: items (waves) per workgroup
+    const int lds = PACK ? G * (lds_item > 4096 ? lds_item : 4096) : lds_item;
     static bool attr_set_d[HG_MAX_DEVICES] = {};      // function attributes are per device
     bool& attr_set = attr_set_d[current_device_index()];
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<CAUSAL, ROW0>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<CAUSAL, ROW0, PACK>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 7 * TILEB);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -172,15 +185,23 @@ static hipError_t launch_t(const half_t* qkv, half_t* out, int n_seq, int L, int
 #else
     constexpr int mode = 0;
 #endif
-    hipLaunchKernelGGL((attention_kernel<CAUSAL, ROW0>), dim3(n_seq * heads), dim3(64 * nkt), lds, s, qkv, out, L, heads, nkt, q0, sel,
-                       mode, ldo);
+    const int n_items = n_seq * heads;
+    if constexpr (PACK)
+        hipLaunchKernelGGL((attention_kernel<CAUSAL, ROW0, true>), dim3((n_items + G - 1) / G), dim3(64 * G), lds, s, qkv, out, L, heads,
+                           nkt, q0, sel, mode, ldo, n_items);
+    else
+        hipLaunchKernelGGL((attention_kernel<CAUSAL, ROW0, false>), dim3(n_items), dim3(64 * nkt), lds, s, qkv, out, L, heads, nkt, q0,
+                           sel, mode, ldo, n_items);
     return hipGetLastError();
 }
 
 hipError_t launch_attention(const half_t* qkv, half_t* out, int n_seq, int L, int heads, bool causal,
-                            hipStream_t s, int ldo) {
+                            hipStream_t s, int ldo, bool pack) {
     if (n_seq <= 0) return hipSuccess;
     if (L < 1 || L > 224 || (ldo != 0 && (ldo < heads * HD || ldo % 8))) return hipErrorInvalidValue;
+    if (pack && L <= 32)      // one wave per item: four items per workgroup (same bits)
+        return causal ? launch_t<true, false, true>(qkv, out, n_seq, L, heads, s, nullptr, nullptr, ldo)
+                      : launch_t<false, false, true>(qkv, out, n_seq, L, heads, s, nullptr, nullptr, ldo);
     return causal ? launch_t<true>(qkv, out, n_seq, L, heads, s, nullptr, nullptr, ldo)
                   : launch_t<false>(qkv, out, n_seq, L, heads, s, nullptr, nullptr, ldo);
 }

@@ -102,8 +102,9 @@ hipError_t launch_gemm_duo(int epi, const GemmArgs& a, hipStream_t s);
 // qkv fp16 [n_seq*L, 3*D] rows = tokens (q|k|v column blocks, head h = 64h..64h+63);
 // out fp16 [n_seq*L, D].  L <= 224.
 // ldo: row stride of out in halfs (0 = heads * 64)
+// pack: L <= 32 (one wave per item) runs four items per workgroup (dispatch-bound otherwise; bit-identical)
 hipError_t launch_attention(const half_t* qkv, half_t* out, int n_seq, int L, int heads, bool causal,
-                            hipStream_t s, int ldo = 0);
+                            hipStream_t s, int ldo = 0, bool pack = true);
 // attention of ONE query row per sequence (row sel[seq], row 0 when sel is null; sel[seq] < L): K and V from
 // qkv [n_seq*L, 3*heads*64], the queries from q0 [n_seq, heads*64] (dense), out [n_seq, heads*64] (dense)
 hipError_t launch_attention_row0(const half_t* qkv, const half_t* q0, const int32_t* sel, half_t* out, int n_seq, int L,

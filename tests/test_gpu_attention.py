@@ -57,6 +57,21 @@ def test_attention_vs_fp32_reference(ctx, n_seq, L, heads, causal):
     assert torch.equal(got, run_full(ctx, qkv, n_seq, L, heads, causal)), "deterministic"
 
 
+@pytest.mark.parametrize("n_seq,L,heads,causal", [(5, 13, 8, True), (301, 14, 8, True), (7, 16, 3, False), (9, 17, 8, True),
+                                                   (33, 32, 2, True), (3, 1, 2, False)])
+def test_short_sequences_packed_four_to_a_workgroup_are_bit_identical(ctx, n_seq, L, heads, causal):
+    """L <= 32 is one query tile = one wave per (sequence, head): the launcher runs four such items per workgroup (the generation
+    pipeline's 14-token prompts were bound by the workgroup dispatch rate).  Same instruction sequence per wave: bit-identical to the
+    one-workgroup-per-item launch (test hook: causal bit 1), ragged item counts (not a multiple of four) included; and against fp32."""
+    g = torch.Generator(device="cuda").manual_seed(L * 7 + heads + n_seq)
+    qkv = torch.randn(n_seq * L, 3 * heads * 64, device="cuda", generator=g) * 1.5
+    packed = run_full(ctx, qkv, n_seq, L, heads, int(causal))
+    single = run_full(ctx, qkv, n_seq, L, heads, int(causal) | 2)
+    assert torch.equal(packed, single)
+    want = ref_attention(qkv, n_seq, L, heads, causal)
+    assert (packed - want).abs().max().item() <= 2e-3 * want.abs().max().item()
+
+
 @pytest.mark.parametrize("n_seq,L,heads,causal", [(9, 197, 12, False), (7, 77, 8, True), (5, 13, 8, True),
                                                    (3, 224, 2, True), (4, 33, 4, False)])
 def test_one_row_variant_is_the_full_kernels_row(ctx, n_seq, L, heads, causal):
