@@ -43,6 +43,8 @@ struct BlockW {
     // MFMA fragments per head pair); null when the width does not qualify
     half_t* wp_qkv;
     float* bcs_qkv;
+    // c_fc / c_proj as the fragment stream of the one-kernel MLP block (hg_vae_fused.hip, mode 3): width 512 only (the text tower)
+    half_t* wp_mlp;
 };
 
 struct AdapterW {
@@ -144,6 +146,8 @@ struct hg_ctx {
     int opt_qkv_attn_min_seq = 32;   // ... from this many sequences per call on, and where its last round of items is filled well
                                      // enough (qkv_attn_pays; qkv_attn = 2: wherever the shapes allow)
     int opt_qkv_attn_gsz = 0;    // head pairs per XCD group of that kernel (0 = all)
+    int opt_mlp_fused = 1;       // blocks of width 512 (text tower): c_fc -> QuickGELU -> c_proj -> residual as ONE kernel for the rows that fill
+                                 // whole rounds of 128-row items (hg_vae_fused.hip, mode 3); 2: every row; 0: the two GEMMs
     int opt_vae_fused = 1;       // CoOp-VAE Encoder -> reparameterise -> Generator as ONE kernel (hg_vae_fused.hip) for the rows that fill
                                  // whole rounds of 128-row items over the CUs (the rest: the GEMM path); 2: every row; 0: GEMM path only
     int n_cu = 256;
@@ -311,6 +315,11 @@ int load_blocks(hg_ctx* c, std::vector<void*>& owned, const hg_block_weights* sr
         keep_first(rc, as_f32(c, owned, s.ln_2_weight, D, &b.ln2_w, "ln_2.weight"));
         keep_first(rc, as_f32(c, owned, s.ln_2_bias, D, &b.ln2_b, "ln_2.bias"));
         if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
+        if (vae_fused_ok(D, 0, 4 * D)) {      // (D = 512: the MLP of the block as one kernel, its hidden layer on chip)
+            keep_first(rc, dev_alloc(c, owned, vae_fused_pass_bytes(4 * D), (void**)&b.wp_mlp));
+            if (rc) return rc < 0 ? rc : HG_ERR_OOM;
+            HG_HIP(launch_pack_vae(nullptr, nullptr, 0, b.w_fc, b.w_proj, 4 * D, b.wp_mlp, 0));
+        }
         if (!fold_ln) continue;
         keep_first(rc, dev_alloc(c, owned, (size_t)3 * D * D * 2, (void**)&b.wf_qkv));
         keep_first(rc, dev_alloc(c, owned, (size_t)3 * D * 4, (void**)&b.cs_qkv));
@@ -509,6 +518,19 @@ inline int chunk_rows(const hg_ctx* c, int left) {
     return left <= m + m / 8 ? left : m;
 }
 
+// Rows (from row 0) that go to the one-kernel path: its work items are 128 rows and take 0.3-0.4 ms each, so it only pays for whole
+// rounds of items over the CUs (100 000 rows = 782 items = 3 rounds of 256 + 14: the 14 would cost a fourth round); the rest - and calls
+// too small to fill most of one round - take the GEMM path, whose 256 x 256 tiles quantise a hundred times finer.
+inline int fused_item_rows(const hg_ctx* c, int opt, int R) {
+    if (opt == 0 || R <= 0) return 0;
+    if (opt == 2) return R;
+    const int per = vae_fused_rows_per_item();
+    const long items = ((long)R + per - 1) / per, ncu = c->n_cu;
+    const long full = items / ncu * ncu, rem = items - full;
+    const long take = full + (rem * 100 >= ncu * 70 ? rem : 0);
+    const long rows = take * per;
+    return (int)(rows < R ? rows : R);
+}
 // hipEvent pair around one launch when its kind is being profiled
 struct ProfScope {
     hg_ctx* c;
@@ -789,16 +811,35 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         }
         g = GemmArgs{};
         g.A = h; g.lda = D; g.out = fc; g.ldc = 4 * D; g.M = M; g.N = 4 * D; g.K = D;
+        int mlp_done = 0;      // leading rows whose MLP ran as the one kernel (separate-LayerNorm path, width 512)
         if (fuse) {
             g.W = b.wf_fc; g.bias = b.bf_fc; g.cs = b.cs_fc; g.mr = mr;
             HG_HIP(gemm(c, EPI_LN_BIAS_QGELU_F16, g, s));
         } else {
             HG_HIP(launch_layernorm_f16(x, b.ln2_w, b.ln2_b, h, M, D, nullptr, 0, 1, s));
-            g.W = b.w_fc; g.bias = b.b_fc;
-            HG_HIP(gemm(c, EPI_BIAS_QGELU_F16, g, s));
+            // Width 512 (the text tower): x += W_proj quickgelu(W_fc h + b_fc) + b_proj as ONE kernel for the leading rows that fill
+            // whole rounds of its 128-row items (hg_vae_fused.hip mode 3: the [rows, 2048] activation stays on chip); the rest below
+            mlp_done = (b.wp_mlp && !trace) ? fused_item_rows(c, c->opt_mlp_fused, M) : 0;
+            if (mlp_done > 0) {
+                VaeFusedArgs a{};
+                a.x16 = h; a.bias = x; a.wp = b.wp_mlp; a.b0g = b.b_fc; a.b2g = b.b_proj;
+                a.R = mlp_done; a.eh = 0; a.gh = 4 * D; a.mode = 3; a.has_enc = false;
+                ProfScope ps(c, s, HG_PROF_VAE_FUSED, mlp_done, 1, 4 * D);
+                HG_HIP(launch_vae_fused(a, s));
+            }
+            if (mlp_done < M) {
+                g.A = h + (size_t)mlp_done * D; g.M = M - mlp_done;
+                g.W = b.w_fc; g.bias = b.b_fc;
+                HG_HIP(gemm(c, EPI_BIAS_QGELU_F16, g, s));
+            }
+        }
+        if (mlp_done >= M) {
+            if (trace) HG_HIP(launch_copy_rows(x, trace + (size_t)(i + 1) * trace_stride, n_seq, L, D, s));
+            continue;
         }
         g = GemmArgs{};
-        g.A = fc; g.lda = 4 * D; g.W = b.w_proj; g.bias = b.b_proj; g.out = x; g.ldc = D; g.M = M; g.N = D; g.K = 4 * D;
+        g.A = fc; g.lda = 4 * D; g.W = b.w_proj; g.bias = b.b_proj; g.out = x + (size_t)mlp_done * D; g.ldc = D; g.M = M - mlp_done; g.N = D;
+        g.K = 4 * D;
         if (fuse && i + 1 < blocks.size()) {      // the last block is followed by ln_post / ln_final on selected rows
             g.out2 = h_of(i + 1); g.ld2 = ldh_of(i + 1); g.stats = stats; g.stats_ld = sld; g.mu = mu;
             rln_args(g);
@@ -935,7 +976,7 @@ hg_ctx* hg_create(int device) {
                                                            {"HG_LN_FUSE", "ln_fuse"}, {"HG_ADAPTER_FUSE", "adapter_fuse"},
                                                            {"HG_ADAPTER_FOLD", "adapter_fold"}, {"HG_STREAM_HILO", "stream_hilo"},
                                                            {"HG_QKV_ATTN", "qkv_attn"}, {"HG_QKV_ATTN_MIN_SEQ", "qkv_attn_min_seq"},
-                                                           {"HG_QKV_ATTN_GSZ", "qkv_attn_gsz"}, {"HG_VAE_FUSED", "vae_fused"}};
+                                                           {"HG_QKV_ATTN_GSZ", "qkv_attn_gsz"}, {"HG_VAE_FUSED", "vae_fused"}, {"HG_MLP_FUSED", "mlp_fused"}};
     for (auto& o : init)
         if (const char* e = getenv(o.env)) (void)hg_set_option(c, o.key, atoi(e));      // (out-of-range values are ignored)
     c->err.clear();
@@ -966,6 +1007,9 @@ int hg_set_option(hg_ctx* c, const char* key, int value) {
     else if (k == "vae_fused") {
         if (value < 0 || value > 2) return fail(c, HG_ERR_INVALID, "vae_fused must be 0, 1 or 2 (got %d)", value);
         c->opt_vae_fused = value;
+    } else if (k == "mlp_fused") {
+        if (value < 0 || value > 2) return fail(c, HG_ERR_INVALID, "mlp_fused must be 0, 1 or 2 (got %d)", value);
+        c->opt_mlp_fused = value;
     }
     else return fail(c, HG_ERR_INVALID, "unknown option '%s'", key);
     return HG_OK;
@@ -985,6 +1029,7 @@ int hg_get_option(hg_ctx* c, const char* key, int* value) {
     else if (k == "qkv_attn_min_seq") *value = c->opt_qkv_attn_min_seq;
     else if (k == "qkv_attn_gsz") *value = c->opt_qkv_attn_gsz;
     else if (k == "vae_fused") *value = c->opt_vae_fused;
+    else if (k == "mlp_fused") *value = c->opt_mlp_fused;
     else return fail(c, HG_ERR_INVALID, "unknown option '%s'", key);
     return HG_OK;
 }
@@ -1844,19 +1889,7 @@ int hg_token_embedding(hg_ctx* c, const int32_t* ids, int n, float* out, void* s
 }
 
 // ---- CoOp-VAE ---------------------------------------------------------------------------------------------
-// Rows (from row 0) that go to the one-kernel path: its work items are 128 rows and take 0.3-0.4 ms each, so it only pays for whole
-// rounds of items over the CUs (100 000 rows = 782 items = 3 rounds of 256 + 14: the 14 would cost a fourth round); the rest - and calls
-// too small to fill most of one round - take the GEMM path, whose 256 x 256 tiles quantise a hundred times finer.
-static int vae_fused_rows(const hg_ctx* c, int R) {
-    if (c->opt_vae_fused == 0 || R <= 0) return 0;
-    if (c->opt_vae_fused == 2) return R;
-    const int per = vae_fused_rows_per_item();
-    const long items = ((long)R + per - 1) / per, ncu = c->n_cu;
-    const long full = items / ncu * ncu, rem = items - full;
-    const long take = full + (rem * 100 >= ncu * 70 ? rem : 0);
-    const long rows = take * per;
-    return (int)(rows < R ? rows : R);
-}
+static int vae_fused_rows(const hg_ctx* c, int R) { return fused_item_rows(c, c->opt_vae_fused, R); }
 static int generator_rows(hg_ctx* c, Vae& v, const half_t* z16, int R, float* bias, hipStream_t s) {
     // Generator: relu(z W0^T + b0) W2^T + b2  (main_coop_vae.py:282-296)
     half_t* g1 = (half_t*)c->fc.p;

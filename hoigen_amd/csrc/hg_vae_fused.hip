@@ -35,6 +35,9 @@
 //           wave-private scratch, E1's half straight into the registers x leaves);
 //   G       the generator on those fragments; epilogue: + bias, fp32 output.
 // Generator-only calls (hg_generator) run pass G alone with z read like x.
+//   M       (mode 3) the MLP of a transformer block of width 512 (the CLIP text tower: clipnet/model.py:173-177,187): the same pass with
+//           QuickGELU in place of relu and the residual update as its epilogue:  x += W_proj quickgelu(W_fc h + b_fc) + b_proj,  h = the
+//           fp16 LayerNorm output (row-major), x the fp32 stream in place.  c_fc's [rows, 2048] activation never reaches HBM.
 //
 // Arithmetic: fp16 operands (x, h, z, g, weights), fp32 accumulate and fp32 bias / relu / reparameterisation - the same roundings as the
 // GEMM path of hg_api.hip (which stores h and g as fp16 in HBM), in a different summation order.
@@ -93,7 +96,7 @@ struct VaeFusedDev {
     const float* b2g;        // [512]
     half_t* zpark;           // [items][4 waves][16 fragments][64 lanes][8] fp16
     int R, nbe, nbg;         // hidden blocks of 32
-    int mode;                // 0 Encoder + Generator, 1 Encoder, 2 Generator
+    int mode;                // 0 Encoder + Generator, 1 Encoder, 2 Generator, 3 MLP block (QuickGELU, bias = the fp32 stream, updated in place)
     int stages_per_item;
     int n_items;
     unsigned long long* dbg;
@@ -233,8 +236,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     else if (pos == 0)
                         asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(hacc[C]) : "v"(wr[pos & 7]), "v"(bf[pos]), "v"(bias16));
                     else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(hacc[C]) : "v"(wr[pos & 7]), "v"(bf[pos]));
-                    // under it: block t - 1 -> fp16 pairs (positions 2..9), relu as a packed fp16 max (10..17)
-                    if (pos >= 2 && pos < 10) {
+                    // under it: block t - 1 -> fp16.  QuickGELU (KIND 3): one element every other MFMA gap (two quarter-rate
+                    // transcendentals each); relu: fp16 pairs (positions 2..9), then a packed fp16 max (10..17)
+                    if constexpr (KIND == 3) {
+                        if ((pos & 1) == 0) {
+                            const int r = pos >> 1;
+                            hf[r >> 3][r & 7] = (half_t)quick_gelu_r(hacc[1 - C][r]);
+                        }
+                    } else if (pos >= 2 && pos < 10) {
                         const int r = 2 * (pos - 2);
                         hp2[pos - 2] = __builtin_convertvector(f32x2t{hacc[1 - C][r], hacc[1 - C][r + 1]}, half2t);
                     } else if (pos >= 10 && pos < 18) {
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const unsigned rbytes = (unsigned)p.R * (VF_DIM * 4);
             const unsigned voff = (unsigned)(item * VF_ROWS + wave * 32 + (l_now & 31)) * (VF_DIM * 4) + 16 * (l_now >> 5);
             const unsigned boff = 16 * (l_now >> 5);
-            if constexpr (KIND == 2) {
+            if constexpr (KIND >= 2) {
                 const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, rbytes, 0x00020000);
                 const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.b2g, 0, VF_DIM * 4, 0x00020000);
 #pragma unroll
@@ -284,7 +293,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     for (int g = 0; g < 4; ++g) {
                         const int cb = (32 * ob + 8 * g) * 4;
                         const f32x4 b2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, boff + cb, 0, 0));
-                        const f32x4 v = f32x4{oacc[ob][4 * g], oacc[ob][4 * g + 1], oacc[ob][4 * g + 2], oacc[ob][4 * g + 3]} + b2;
+                        f32x4 v = f32x4{oacc[ob][4 * g], oacc[ob][4 * g + 1], oacc[ob][4 * g + 2], oacc[ob][4 * g + 3]} + b2;
+                        if constexpr (KIND == 3)      // the residual update: x += (acc + bias), this lane's own four columns in place
+                            v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsO, voff + cb, 0, 0)) + v;
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsO, voff + cb, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -351,6 +362,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     using K0 = std::integral_constant<int, 0>;
     using K1 = std::integral_constant<int, 1>;
     using K2 = std::integral_constant<int, 2>;
+    using K3 = std::integral_constant<int, 3>;
 
     for (item = blockIdx.x; item < p.n_items; item += gridDim.x) {
         // ---- the wave's rows as B fragments: element j of lane (n, h) in k-step s = x[row n][vf_kidx(s, h, j)]  (rows beyond R: zeros)
@@ -383,11 +395,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
         VF_STAMP_E(tk_x);
-        if (p.mode != 2) {
-            run_pass(K0{}, p.nbe, p.b0e);
-            run_pass(K1{}, p.nbe, p.b0e);
+        if (p.mode == 3) run_pass(K3{}, p.nbg, p.b0g);
+        else {
+            if (p.mode != 2) {
+                run_pass(K0{}, p.nbe, p.b0e);
+                run_pass(K1{}, p.nbe, p.b0e);
+            }
+            if (p.mode != 1) run_pass(K2{}, p.nbg, p.b0g);
         }
-        if (p.mode != 1) run_pass(K2{}, p.nbg, p.b0g);
     }
     wait_vm<0>();
 #ifdef HG_STAMPS
@@ -462,11 +477,11 @@ hipError_t launch_pack_vae(const half_t* e_w0, const half_t* e_wml, int eh, cons
 }
 
 hipError_t launch_vae_fused(const VaeFusedArgs& a, hipStream_t s) {
-    if (a.R <= 0 || (!a.x && !(a.mode == 2 && a.x16)) || !a.wp || a.mode < 0 || a.mode > 2) return hipErrorInvalidValue;
-    if (a.mode != 2 && (!a.eps || !a.b0e || !a.bml || !a.zpark)) return hipErrorInvalidValue;
+    if (a.R <= 0 || (!a.x && !(a.mode >= 2 && a.x16)) || !a.wp || a.mode < 0 || a.mode > 3) return hipErrorInvalidValue;
+    if (a.mode < 2 && (!a.eps || !a.b0e || !a.bml || !a.zpark)) return hipErrorInvalidValue;
     if (a.mode != 1 && (!a.b0g || !a.b2g || !a.bias)) return hipErrorInvalidValue;
     VaeFusedDev d{};
-    d.x = a.x; d.x16 = a.mode == 2 ? a.x16 : nullptr; d.eps = a.eps; d.mean = a.mean; d.logvar = a.logvar; d.z = a.z; d.bias = a.bias;
+    d.x = a.x; d.x16 = a.mode >= 2 ? a.x16 : nullptr; d.eps = a.eps; d.mean = a.mean; d.logvar = a.logvar; d.z = a.z; d.bias = a.bias;
     d.b0e = a.b0e; d.bml = a.bml; d.b0g = a.b0g; d.b2g = a.b2g; d.zpark = a.zpark;
     d.R = a.R; d.nbe = a.eh / 32; d.nbg = a.gh / 32;
     const size_t enc_bytes = 2 * vae_fused_pass_bytes(a.eh), gen_bytes = vae_fused_pass_bytes(a.gh);
@@ -475,7 +490,8 @@ hipError_t launch_vae_fused(const VaeFusedArgs& a, hipStream_t s) {
     d.mode = a.mode;
     if (a.mode == 0) bytes = enc_bytes + gen_bytes;
     else if (a.mode == 1) bytes = enc_bytes;
-    else { d.wp = a.wp + (a.has_enc ? enc_bytes / 2 : 0); bytes = gen_bytes; }
+    else if (a.mode == 2) { d.wp = a.wp + (a.has_enc ? enc_bytes / 2 : 0); bytes = gen_bytes; }
+    else bytes = gen_bytes;      // mode 3: wp is the one pass of this block's MLP
     if (bytes >= (1ull << 31) || a.R > (1 << 20)) return hipErrorInvalidValue;      // (32-bit byte offsets into the [R, 512] fp32 tensors)
     d.stages_per_item = (int)(bytes / VF_STAGE);
     d.n_items = (a.R + VF_ROWS - 1) / VF_ROWS;

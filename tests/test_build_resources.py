@@ -48,8 +48,8 @@ def test_no_kernel_spills_registers_or_uses_scratch():
     # half of a 64-bit store offset - are now made where they are used.  No VGPR spill, no scratch: nothing is tolerated here.)
     # vae_fused_kernel (hg_vae_fused.hip) holds 256 accumulator + 128 operand registers through its pass loops; at the joins between
     # its three pass epilogues the allocator parks one accumulator block (16 + 4 dwords) in scratch for the duration of an epilogue
-    # (three per 128-row item of ~0.3 ms).  Its pass LOOPS must be free of scratch and vmcnt(0): test_vae_fused_pass_loops_are_scratch_free.
-    few_ok = {"vae_fused_kernel": 24}
+    # (three per 128-row item of ~0.3 ms; 36 dwords in all with the MLP-block pass).  Its pass LOOPS must be free of scratch and vmcnt(0): test_vae_fused_pass_loops_are_scratch_free.
+    few_ok = {"vae_fused_kernel": 40}
     def tolerated(r):
         f, n, k, v = r
         if k == "SGPRs Spill" and any(x in n for x in sgpr_ok):
@@ -84,7 +84,7 @@ def test_fused_kernel_k_loop_is_scratch_free():
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_vae_fused_pass_loops_are_scratch_free():
-    """The three pass loops of vae_fused_kernel (two iterations of 64 MFMAs per trip) keep six ring stages of LDS-DMA in flight behind
+    """The four pass loops of vae_fused_kernel (two iterations of 64 MFMAs per trip) keep six ring stages of LDS-DMA in flight behind
     counted s_waitcnt vmcnt(20): a scratch reload inside them waits for vmcnt(0) and drains the ring once per iteration (measured:
     4 750 instead of 2 100 cycles per iteration).  Every innermost loop that holds MFMAs must hold exactly 128 of them, 8 barriers,
     no scratch access, no vmcnt(0), and no AGPR<->VGPR copies (the layer-1 accumulators are VGPR-form inline asm for that reason)."""
@@ -101,7 +101,7 @@ def test_vae_fused_pass_loops_are_scratch_free():
         if m and m.group(1) in labels and labels[m.group(1)] < i:
             loops.append((labels[m.group(1)], i))
     inner = [(a, b) for a, b in loops if sum("v_mfma" in x for x in lines[a:b + 1]) == 128]
-    assert len(inner) == 3, f"expected the three pass loops, found {len(inner)}"
+    assert len(inner) == 4, f"expected the four pass loops (Encoder x 2, Generator, MLP block), found {len(inner)}"
     for a, b in inner:
         body = lines[a:b + 1]
         assert sum("s_barrier" in x for x in body) == 8

@@ -169,19 +169,33 @@ def test_text_700_prompts_equals_chunks(fullA, g0):
         ids[i, :len(r)] = r
     ids = torch.from_numpy(ids).to(dev())
     assert ids.shape[0] == 1000
-    for trunc in (False, True):
-        fullA.truncate_text = trunc
-        whole = fullA.encode_text(ids)
-        # truncation length = max(EOT)+1 over the CALL: give the pieces the same length by keeping the longest
-        # prompt of the whole set in every piece
-        longest = int(ids.argmax(dim=-1).argmax())
-        for lo, hi in ((0, 500), (500, 1000), (490, 510), (0, 640)):
-            sel = torch.arange(lo, hi, device=ids.device)
-            if trunc and not (lo <= longest < hi):
-                sel = torch.cat([sel, torch.tensor([longest], device=ids.device)])
-            part = fullA.encode_text(ids[sel])[: hi - lo]
-            assert torch.equal(part, whole[lo:hi]), f"prompts [{lo},{hi}) truncate={trunc}"
-    fullA.truncate_text = True
+    # (option mlp_fused: a row's MLP runs as the one kernel or as two GEMMs depending on where it falls in its pass - the bits of a row
+    # depend on that path, never on its neighbours: each path is held to bit-equality on its own, the default against both)
+    wholes = {}
+    try:
+        for mlp in (0, 2, 1):
+            fullA.set_option("mlp_fused", mlp)
+            for trunc in (False, True):
+                fullA.truncate_text = trunc
+                whole = wholes[mlp, trunc] = fullA.encode_text(ids)
+                if mlp == 1:
+                    for other in (0, 2):
+                        err = float((whole.float() - wholes[other, trunc].float()).norm() / wholes[other, trunc].float().norm())
+                        assert err < 3e-4, f"mlp_fused=1 vs {other}, truncate={trunc}: {err:.2e}"
+                    continue
+                # truncation length = max(EOT)+1 over the CALL: give the pieces the same length by keeping the longest
+                # prompt of the whole set in every piece
+                longest = int(ids.argmax(dim=-1).argmax())
+                for lo, hi in ((0, 500), (500, 1000), (490, 510), (0, 640)):
+                    sel = torch.arange(lo, hi, device=ids.device)
+                    if trunc and not (lo <= longest < hi):
+                        sel = torch.cat([sel, torch.tensor([longest], device=ids.device)])
+                    part = fullA.encode_text(ids[sel])[: hi - lo]
+                    assert torch.equal(part, whole[lo:hi]), f"prompts [{lo},{hi}) truncate={trunc} mlp_fused={mlp}"
+        assert not torch.equal(wholes[0, False], wholes[2, False]), "option mlp_fused did not change the executed path"
+    finally:
+        fullA.set_option("mlp_fused", 1)
+        fullA.truncate_text = True
 
 
 def test_prompt_learner_fp16_buffers_and_renamed_classes(fullA, g0):
