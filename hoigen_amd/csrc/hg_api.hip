@@ -146,8 +146,10 @@ struct hg_ctx {
     int opt_qkv_attn_min_seq = 32;   // ... from this many sequences per call on, and where its last round of items is filled well
                                      // enough (qkv_attn_pays; qkv_attn = 2: wherever the shapes allow)
     int opt_qkv_attn_gsz = 0;    // head pairs per XCD group of that kernel (0 = all)
-    int opt_mlp_fused = 1;       // blocks of width 512 (text tower): c_fc -> QuickGELU -> c_proj -> residual as ONE kernel for the rows that fill
-                                 // whole rounds of 128-row items (hg_vae_fused.hip, mode 3); 2: every row; 0: the two GEMMs
+    int opt_mlp_fused = 0;       // blocks of width 512 (text tower): 1 = c_fc -> QuickGELU -> c_proj -> residual as ONE kernel for the rows that
+                                 // fill whole rounds of 128-row items (hg_vae_fused.hip, mode 3), 2 = every row, 0 (default) = the two GEMMs:
+                                 // measured a tie (65 534-row pass: 331-335 us against 161 + 190; the generation pipeline -1.4 %) and a loss
+                                 // where a call leaves a remainder (600 prompts x 77 tokens: 5.47 -> 5.66 ms)
     int opt_vae_fused = 1;       // CoOp-VAE Encoder -> reparameterise -> Generator as ONE kernel (hg_vae_fused.hip) for the rows that fill
                                  // whole rounds of 128-row items over the CUs (the rest: the GEMM path); 2: every row; 0: GEMM path only
     int n_cu = 256;

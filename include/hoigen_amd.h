@@ -252,6 +252,9 @@ int hg_vae_loss(hg_ctx*, const float* recon, const float* x, const float* mean, 
  *                      up to 4096) for the leading rows that fill whole rounds of its 128-row work items over the CUs, the GEMM path for
  *                      the rest (and for calls too small to fill 70 % of one round); 2: the one kernel for every row; 0: GEMM path only.
  *                      Same fp16 operand roundings on both paths; results differ by fp32 summation order.
+ *   "mlp_fused"       [HG_MLP_FUSED]       blocks of width 512 (the text tower, separate-LayerNorm path): 1 = c_fc -> QuickGELU -> c_proj ->
+ *                      residual as ONE kernel (hg_vae_fused.hip mode 3: the [rows, 2048] activation stays on chip) for the leading rows that
+ *                      fill whole rounds of 128-row items, 2 = every row, 0 (default: measured a tie) = the two GEMMs
  *   "chunk_rows"      [HG_CHUNK_ROWS]      rows per VAE / mlp_net / cache-logits chunk (>= 256; default 32768; the last chunk of a
  *                      call absorbs a tail of up to an eighth of it)
  * Unknown keys and out-of-range values return HG_ERR_INVALID. */

