@@ -56,8 +56,12 @@ namespace {
 constexpr int VF_DIM = 512;                  // feature width (x, mean, log_var, z, bias)
 constexpr int VF_KS = VF_DIM / 16;           // k-steps of a row = B fragments per wave
 constexpr int VF_ROWS = 128;                 // rows per item (4 waves x 32)
-constexpr int VF_STAGE = 16 * 1024;          // one ring stage = 16 fragments
-constexpr int VF_NS = 8;                     // ring slots
+#ifndef VF_STAGE_KB
+#define VF_STAGE_KB 16
+#endif
+constexpr int VF_STAGE = VF_STAGE_KB * 1024; // one ring stage = 16 (32) fragments: one s_barrier per stage
+constexpr int VF_NS = 128 / VF_STAGE_KB;     // ring slots (128 KiB)
+constexpr int VF_WPIECES = VF_STAGE / 4096;  // 1-KiB pieces of a stage per wave
 constexpr int VF_ITER_BYTES = 64 * 1024;     // one iteration = 64 fragments = 4 stages = half the ring
 constexpr int VF_RING = 0;
 constexpr int VF_TAB = VF_NS * VF_STAGE;     // first-layer bias of the pass: (nb + 2) x 32 floats
@@ -138,16 +142,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // A boundary is the only non-MFMA work of the loop that does not hide under an MFMA (the wave issues in order): kept to a dozen
     // scalar instructions - one M0, the four pieces as immediate offsets (they apply to the LDS side as well).
     const int stream_bytes = p.stages_per_item * VF_STAGE;
-    int d_off = wave * 4096;
-    int d_lds = VF_RING + wave * 4096;
+    int d_off = wave * (VF_STAGE / 4);
+    int d_lds = VF_RING + wave * (VF_STAGE / 4);
     auto issue_stage = [&]() {
         if (!(xmode & 1)) {
             const int lane16 = lane_now() * 16;
-            const int off = (xmode & 2) ? wave * 4096 : d_off;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (HG_LDS void*)(smem + d_lds), 16, lane16, off, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (HG_LDS void*)(smem + d_lds), 16, lane16, off, 1024, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (HG_LDS void*)(smem + d_lds), 16, lane16, off, 2048, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (HG_LDS void*)(smem + d_lds), 16, lane16, off, 3072, 0);
+            const int off = (xmode & 2) ? wave * (VF_STAGE / 4) : d_off;
+#pragma unroll
+            for (int g4 = 0; g4 < VF_WPIECES / 4; ++g4) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (HG_LDS void*)(smem + d_lds + g4 * 4096), 16, lane16, off + g4 * 4096, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (HG_LDS void*)(smem + d_lds + g4 * 4096), 16, lane16, off + g4 * 4096, 1024, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (HG_LDS void*)(smem + d_lds + g4 * 4096), 16, lane16, off + g4 * 4096, 2048, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (HG_LDS void*)(smem + d_lds + g4 * 4096), 16, lane16, off + g4 * 4096, 3072, 0);
+            }
         }
         d_off += VF_STAGE;
         if (d_off >= stream_bytes) d_off -= stream_bytes;
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // is past the stage two back: refill its slot
     auto boundary = [&]() {
         VF_STAMP_B();
-        if (!(xmode & 1)) wait_vm<(VF_NS - 3) * 4>();
+        if (!(xmode & 1)) wait_vm<(VF_NS - 3) * VF_WPIECES>();
         VF_STAMP_E(tk_vm);
         VF_STAMP_B();
         barrier_raw();
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int pos = 0; pos < 64; ++pos) {
                 const int q = pos + VF_AHEAD;
-                if ((q & 15) == 0) boundary();
+                if ((q & (VF_STAGE / 1024 - 1)) == 0) boundary();
                 if (!(xmode & 8)) wr[q & 7] = q < 64 ? rd(base_cur, q) : rd(base_nxt, q - 64);
                 if (pos < 32) {
                     // layer 1 of block t: H^T += W0frag x x^T frag
