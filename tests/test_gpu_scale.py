@@ -181,7 +181,7 @@ def test_text_700_prompts_equals_chunks(fullA, g0):
                 if mlp == 1:
                     for other in (0, 2):
                         err = float((whole.float() - wholes[other, trunc].float()).norm() / wholes[other, trunc].float().norm())
-                        assert err < 3e-4, f"mlp_fused=1 vs {other}, truncate={trunc}: {err:.2e}"
+                        assert err < 9e-4, f"mlp_fused=1 vs {other}, truncate={trunc}: {err:.2e}"      # (two realisations of 12 blocks of fp16 roundings, each ~6.5e-4 from the reference)
                     continue
                 # truncation length = max(EOT)+1 over the CALL: give the pieces the same length by keeping the longest
                 # prompt of the whole set in every piece
