@@ -635,12 +635,14 @@ __global__ __launch_bounds__(F == 2 ? 512 : 256) void adapter_decoder_mfma(const
     for (int f = 0; f < F; ++f)
         if (tok[f] < L) {
             half_t* dst = out16 + ((size_t)seq * L + tok[f]) * ld16;
+            half_t* dst2 = FD.e2 ? FD.e2 + ((size_t)seq * L + tok[f]) * ld16 : nullptr;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 half4 h;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) h[e] = (half_t)tgt[f][g][e];
                 *reinterpret_cast<half4*>(dst + 16 * g + 4 * q) = h;
+                if (dst2) *reinterpret_cast<half4*>(dst2 + 16 * g + 4 * q) = h;
             }
         }
 }

@@ -130,6 +130,7 @@ struct hg_ctx {
     Cache cache[HG_MAX_CACHE_SLOTS];
     // workspace (grow-only)
     Buf x, h, qkv, att, fc, head16, tok32, small, i32, ad32, ad16, adkv, mr, mu, muc, stats, pre, pretab, cx, ca, ch, cf, cq;
+    Buf att2;            // variant C with the stream as centre + hi + lo: the out-proj operand [att | e] beside the in_proj one [x16 | e]
     Buf zpark;           // hg_vae_fused.hip: the encoder's first z half as fp16 fragments, per wave
     Buf xlo;             // low half of the residual stream while it is held as centre + hi + lo (GemmArgs::hl)
     int max_chunk_img = 256;
@@ -577,7 +578,7 @@ struct AdapterCall {
 // centred fp16 copy of the stream is expected in columns 0..D-1 of c->att (row stride D + 64), the decoder writes e beside it and
 // turns c->mr into the statistics of x + a; the block's QKV GEMM then takes [x16 | e] x [W'_qkv | W'_qkv Q]
 int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const AdapterCall& ac, hipStream_t s, bool fused,
-                int kcat = 0);
+                int kcat = 0, half_t* e2 = nullptr);
 
 // LayerNorm folded into the GEMMs: the residual GEMMs (out-proj, c_proj) also emit the fp16 copy of the updated
 // rows and per-row partial statistics; the consuming GEMMs (QKV, c_fc) read that copy and apply mean / rstd in
@@ -697,23 +698,32 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
     // hi IS the centred fp16 copy those GEMMs write anyway, lo its remainder as bf8 (HG_LO8; fp16 otherwise) - 6 (8) instead of 10
     // bytes per element through every such epilogue and a third fewer partial-line stores.  The first of them reads the fp32 stream (ln_pre wrote it),
     // the last one writes fp32 again (the plain last c_proj / the class-rows path / ln_post read it); nothing in between
-    // touches x.  Variant A only (the adapters rewrite the stream), and only where the GEMMs run on gemm_ring2.
+    // touches x.  Variant A, and variant C when EVERY block's adapter is folded into its GEMMs (mode 2: nothing but the residual GEMMs
+    // rewrites the stream; round 5): the hi half then lives in the in_proj operand buffer [x16 | e] (row stride D + 64) through the
+    // whole block - attention writes into a second operand buffer [att | e] instead of over it, the decoder writes e into both, c_fc
+    // reads the copy with that stride.  Only where the GEMMs run on gemm_ring2.
     const bool row0_plan = row0_out && row0_env && !adapters;
     const int n_rln = fuse ? (row0_plan ? 2 * ((int)blocks.size() - 1) : 2 * (int)blocks.size() - 1) : 0;
-    bool hilo = fuse && !adapters && c->opt_stream_hilo && n_rln >= 2;
+    bool all_k2 = adapters && !kmode.empty();
+    for (int k : kmode) all_k2 = all_k2 && k == 2;
+    bool hilo = fuse && (!adapters || all_k2) && c->opt_stream_hilo && n_rln >= 2;
     if (hilo) {
         GemmArgs r{};
-        r.M = M; r.N = D; r.ldc = D; r.K = D; r.lda = D;
+        r.M = M; r.N = D; r.ldc = D; r.K = adapters ? D + 64 : D; r.lda = r.K;
         hilo = gemm_ring2_ok(r);
         r.K = 4 * D; r.lda = 4 * D;
         hilo = hilo && gemm_ring2_ok(r);
     }
+    half_t* att2 = nullptr;
     if (hilo) {
         int rc = ensure(c, c->xlo, gemm_lo_bytes(M, D));
         if (!rc) rc = ensure(c, c->muc, rup(M, 256) * 4);
+        if (!rc && adapters) rc = ensure(c, c->att2, rup(M, 256) * (size_t)(D + 64) * 2);
         if (rc) return rc;
         muc = (float*)c->muc.p;
+        att2 = adapters ? (half_t*)c->att2.p : nullptr;
     }
+    const bool hilo_c = hilo && adapters;      // (variant C on the hi / lo stream: att holds [x16 = hi | e], att2 [attention output | e])
     // blocks whose in_proj and attention run as one kernel (option qkv_attn): folded LayerNorm, no adapter in the block's
     // GEMMs, a sequence per row tile (192 < L <= 208), enough sequences to fill the chip
     const bool qa_on = fuse && !causal && c->opt_qkv_attn && n_seq >= c->opt_qkv_attn_min_seq && qkv_attn_ok(n_seq, L, D, heads, D) &&
@@ -738,7 +748,7 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
                 if (rc) return rc;
                 att = (half_t*)c->att.p;
             }
-            int rc = run_adapter(c, aw, n_seq, L, D, *ac, s, fuse, kcat);
+            int rc = run_adapter(c, aw, n_seq, L, D, *ac, s, fuse, kcat, hilo_c ? att2 + D : nullptr);
             if (rc) return rc;
         }
         const bool row0_last = row0_out && row0_env && !adapters && i + 1 == blocks.size();
@@ -797,15 +807,17 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
             *row0_out = cx;
             break;
         }
-        if (!(fuse && qa_block(i, row0_last))) HG_HIP(attention(c, qkv, att, n_seq, L, heads, causal, s, kcat ? D + 64 : 0));
+        half_t* const att_o = hilo_c ? att2 : att;      // where the attention output (the out-proj operand) goes
+        if (!(fuse && qa_block(i, row0_last))) HG_HIP(attention(c, qkv, att_o, n_seq, L, heads, causal, s, kcat ? D + 64 : 0));
         g = GemmArgs{};
-        g.A = att; g.lda = D; g.W = b.w_out; g.bias = b.b_out; g.out = x; g.ldc = D; g.M = M; g.N = D; g.K = D;
+        g.A = att_o; g.lda = D; g.W = b.w_out; g.bias = b.b_out; g.out = x; g.ldc = D; g.M = M; g.N = D; g.K = D;
         if (kcat == 2) {      // x += [att | e] [W_out | Q]^T + b_out: the adapter's update rides along
             g.lda = D + 64; g.K = D + 64; g.W = c->vit.adapters[i].fold[ac->priors ? 0 : 1].wk_out;
         }
         if (fuse) {
             g.out2 = h; g.stats = stats; g.stats_ld = sld; g.mu = mu;
-            if (!kcat) rln_args(g);
+            if (hilo_c) { g.out2 = att; g.ld2 = D + 64; }      // the copy = the stream's hi half stays in [x16 | e]
+            if (!kcat || hilo_c) rln_args(g);
             HG_HIP(gemm(c, EPI_RESID_LN_F32, g, s));
             HG_HIP(launch_finalize_stats(stats, mr, mu, M, sld, 64, s, muc));
         } else {
@@ -816,6 +828,7 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         int mlp_done = 0;      // leading rows whose MLP ran as the one kernel (separate-LayerNorm path, width 512)
         if (fuse) {
             g.W = b.wf_fc; g.bias = b.bf_fc; g.cs = b.cs_fc; g.mr = mr;
+            if (hilo_c) { g.A = att; g.lda = D + 64; }
             HG_HIP(gemm(c, EPI_LN_BIAS_QGELU_F16, g, s));
         } else {
             HG_HIP(launch_layernorm_f16(x, b.ln2_w, b.ln2_b, h, M, D, nullptr, 0, 1, s));
@@ -871,7 +884,7 @@ int ensure_tower_ws(hg_ctx* c, int M, int D) {
 }
 
 int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const AdapterCall& ac, hipStream_t s, bool fused,
-                int kcat) {
+                int kcat, half_t* e2) {
     const int M = n_seq * L;
     float* x = (float*)c->x.p;
     half_t* h = (half_t*)c->h.p;
@@ -919,7 +932,7 @@ int run_adapter(hg_ctx* c, const AdapterW& a, int n_seq, int L, int D, const Ada
             for (int j = 0; j < 6; ++j) ad.w16[0][j] = a.extra[z - 1].w16[j];
         half_t* d16 = kcat ? (half_t*)c->att.p + D : (half_t*)c->ad16.p;
         AdapterFoldDev fd{};
-        if (kcat == 2) { fd.g16 = fold.g16; fd.qm = fold.qm; fd.mr = (float*)c->mr.p; fd.inv_D = 1.0f / (float)D; }
+        if (kcat == 2) { fd.g16 = fold.g16; fd.qm = fold.qm; fd.mr = (float*)c->mr.p; fd.inv_D = 1.0f / (float)D; fd.e2 = e2; }
         AdapterDownDev dn{};
         if (down_fused && z == 0) {
             dn.x16 = (const half_t*)c->att.p; dn.ldx = D + 64; dn.K = D; dn.w = fold.down2; dn.b = a.down_b; dn.cs = a.down_cs;
@@ -1047,7 +1060,7 @@ void hg_destroy(hg_ctx* c) {
     for (auto& m : c->mlp) free_all(m.owned);
     for (auto& m : c->cache) free_all(m.owned);
     Buf* bufs[] = {&c->x, &c->h, &c->qkv, &c->att, &c->fc, &c->head16, &c->tok32, &c->small, &c->i32,
-                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq, &c->xlo, &c->zpark};
+                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq, &c->xlo, &c->zpark, &c->att2};
     for (Buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
@@ -1393,7 +1406,7 @@ int hg_profile_end(hg_ctx* c, hg_prof_rec* recs, int max_recs, int32_t* n_recs) 
 int hg_workspace_bytes(hg_ctx* c, uint64_t* bytes) {
     if (!c || !bytes) return HG_ERR_INVALID;
     Buf* bufs[] = {&c->x, &c->h, &c->qkv, &c->att, &c->fc, &c->head16, &c->tok32, &c->small, &c->i32,
-                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq, &c->xlo, &c->zpark};
+                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq, &c->xlo, &c->zpark, &c->att2};
     uint64_t t = 0;
     for (Buf* b : bufs) t += b->bytes;
     *bytes = t;

@@ -745,7 +745,7 @@ hipError_t launch_gemm_ring2(int epi, const GemmArgs& a_in, hipStream_t s) {
         case EPI_BIAS_RELU_F32: return launch_ring2_t<EPI_BIAS_RELU_F32>(a, s);
         case EPI_SCALE_RESID_F32: return launch_ring2_t<EPI_SCALE_RESID_F32>(a, s);
         case EPI_RESID_LN_F32:
-            if (a.hl && (!a.lo || !a.mu || ((a.hl == 2 || a.hl == 3) && !a.muc) || a.ld2 != a.ldc)) return hipErrorInvalidValue;
+            if (a.hl && (!a.lo || !a.mu || ((a.hl == 2 || a.hl == 3) && !a.muc))) return hipErrorInvalidValue;      // (the hi half lives at out2 with row stride ld2: any)
             switch (a.hl) {
                 case 0: return launch_ring2_t<EPI_RESID_LN_F32, 0>(a, s);
                 case 1: return launch_ring2_t<EPI_RESID_LN_F32, 1>(a, s);

@@ -272,6 +272,7 @@ struct AdapterFoldDev {
     const float* qm = nullptr;     // [64] column sums of Q
     float* mr = nullptr;           // [M][2], updated in place; null = off
     float inv_D = 0.f;
+    half_t* e2 = nullptr;          // a second home of e (row stride ld16): the out-proj operand buffer when it is not the in_proj one
 };
 // dn (MFMA path, first layer of a chain): down_proj runs inside the kernel - [relu(down) | x16 Q] = [x16 + muc] w^T + b with
 // w [128, K] fp16 (AdapterW::Fold::down2), b / cs [128]; down32 is then only written (chain32: the fp32 hand-over to the next

@@ -691,3 +691,35 @@ def test_text_mlp_block_as_one_kernel_vs_reference(fullA, g0):
         fullA.truncate_text = True
     assert not torch.equal(outs[0], outs[2]) and not torch.equal(outs[0], outs[1])
     check(outs[2], outs[0].cpu().numpy(), tol=9e-4, what="one-kernel MLP vs two GEMMs")      # (two realisations of the fp16 roundings of 12 blocks, each 6.5e-4 from the reference)
+
+
+def test_variant_c_on_the_hi_lo_stream_vs_reference():
+    """Round 5: with every block's adapter folded into its GEMMs (the default) variant C holds the residual stream as centre + hi + lo
+    between the residual GEMMs like variant A does (option stream_hilo; the hi half lives in the in_proj operand buffer [x16 | e],
+    attention writes into a second operand buffer [att | e], the decoder writes e into both).  Against the reference's own variant C
+    outputs (g2: with priors and without) on both settings, the settings against each other, 40 crops (the chunk is batch-independent)."""
+    g = dict(np.load(f"{G}/g2_vitb16_image.npz"))
+    sd = synth.to_torch(synth.clip_state_dict(synth.VIT_B16, 0))
+    sd.update(synth.to_torch(synth.adapter_state_dict(synth.VIT_B16, 1)))
+    m = build_model(sd, use_adapter=True).to(dev())
+    torch.manual_seed(3)
+    img = torch.cat([torch.from_numpy(synth.crops(4, 224, seed=1234)).to(dev()), torch.randn(36, 3, 224, 224, device=dev())])
+    pri, mask = synth.priors(4, n=14, dim=64, n_pad=4, seed=99)
+    pri40 = torch.cat([torch.from_numpy(pri).to(dev()), torch.randn(36, 14, 64, device=dev())])
+    mask40 = torch.cat([torch.from_numpy(mask).to(dev()), torch.zeros(36, 14, dtype=torch.bool, device=dev())])
+    outs = {}
+    try:
+        for mode in (1, 0):
+            m.visual.set_option("stream_hilo", mode)
+            gl, lo = m.visual(img, (pri40, mask40))
+            e1 = check(gl[:4], g["c_prior_global"], what=f"C global, stream_hilo={mode}")
+            e2 = check(lo[:4].permute(0, 2, 3, 1), np.transpose(g["c_prior_local"], (0, 2, 3, 1)), what=f"C local, stream_hilo={mode}")
+            gn, ln_ = m.visual(img[:2], None)
+            check(gn, g["c_noprior_global"], what=f"C global no prior, stream_hilo={mode}")
+            check(ln_.permute(0, 2, 3, 1), np.transpose(g["c_noprior_local"], (0, 2, 3, 1)), what=f"C local no prior, stream_hilo={mode}")
+            print(f"\nvariant C rel-L2 vs reference, stream_hilo={mode}: global {e1:.3e} local {e2:.3e}")
+            outs[mode] = (gl, lo)
+    finally:
+        m.visual.set_option("stream_hilo", 1)
+    assert not torch.equal(outs[1][0], outs[0][0]), "the switch did not change the executed path"
+    check(outs[1][0], outs[0][0].cpu().numpy(), what="variant C hi / lo stream vs fp32 stream (global)")
