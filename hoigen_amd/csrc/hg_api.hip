@@ -62,6 +62,7 @@ struct AdapterW {
         half_t* down2 = nullptr;    // [128, D]: down_proj rows | Q^T (the cross term of the statistics rides in the padded half)
         half_t* wk_out = nullptr;   // [D, D + 64] = [W_out | Q]
         half_t* wq_cat = nullptr;   // [3D, D + 64] = [W'_qkv | W'_qkv Q]
+        half_t* wp_qcat = nullptr;  // wq_cat in the fused in_proj + attention kernel's fragment order (launch_pack_qkv, K = D + 64)
         half_t* g16 = nullptr;      // [64, 64] Q^T Q
         float* qm = nullptr;        // [64] column sums of Q
     } fold[2];
@@ -147,6 +148,7 @@ struct hg_ctx {
     int opt_qkv_attn_min_seq = 32;   // ... from this many sequences per call on, and where its last round of items is filled well
                                      // enough (qkv_attn_pays; qkv_attn = 2: wherever the shapes allow)
     int opt_qkv_attn_gsz = 0;    // head pairs per XCD group of that kernel (0 = all)
+    int opt_qkv_attn_c = 1;      // ... also in the blocks that carry a folded adapter (variant C on the hi / lo stream: K = D + 64)
     int opt_mlp_fused = 0;       // blocks of width 512 (text tower): 1 = c_fc -> QuickGELU -> c_proj -> residual as ONE kernel for the rows that
                                  // fill whole rounds of 128-row items (hg_vae_fused.hip, mode 3), 2 = every row, 0 (default) = the two GEMMs:
                                  // measured a tie (65 534-row pass: 331-335 us against 161 + 190; the generation pipeline -1.4 %) and a loss
@@ -499,6 +501,11 @@ int load_adapters(hg_ctx* c, const hg_adapter_weights* src, int layers) {
                 const float* norms = k == 0 ? (a.extra.empty() ? a.dl[0][8] : a.extra.back().dl[8]) : a.dl[1][8];
                 hipError_t e = launch_adapter_fold(a.up_w, a.up_b, a.scale, norms, a.down_w, v.blocks[i].w_out, v.blocks[i].wf_qkv, D,
                                                    q32, f.down2, f.wk_out, f.wq_cat, f.qm, f.g16, 0);
+                if (e == hipSuccess && d == 64 && qkv_attn_ok(1, 197, D, D / 64, D + 64, D + 64)) {
+                    keep_first(rc, dev_alloc(c, own, (size_t)3 * D * (D + d) * 2, (void**)&f.wp_qcat));
+                    if (rc) break;
+                    e = launch_pack_qkv(f.wq_cat, nullptr, nullptr, f.wp_qcat, nullptr, D, D / 64, 0, D + 64);
+                }
                 if (e == hipSuccess) e = hipDeviceSynchronize();
                 if (e != hipSuccess) rc = fail(c, HG_ERR_HIP, "adapter fold failed: %s", hipGetErrorString(e));
             }
@@ -728,7 +735,14 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
     // GEMMs, a sequence per row tile (192 < L <= 208), enough sequences to fill the chip
     const bool qa_on = fuse && !causal && c->opt_qkv_attn && n_seq >= c->opt_qkv_attn_min_seq && qkv_attn_ok(n_seq, L, D, heads, D) &&
                        (c->opt_qkv_attn == 2 || qkv_attn_pays(n_seq, heads, 0));
-    auto qa_block = [&](size_t i, bool row0_last_blk) { return qa_on && !row0_last_blk && kmode[i] == 0 && blocks[i].wp_qkv != nullptr; };
+    // (variant C on the hi / lo stream: the same kernel over K = D + 64, [x16 | e] in att -> att2; without the second buffer the
+    // attention output overwrites x16 in place, which other work items of the sequence are still reading)
+    auto qa_block = [&](size_t i, bool row0_last_blk) {
+        if (!qa_on || row0_last_blk || blocks[i].wp_qkv == nullptr) return false;
+        if (kmode[i] == 0) return true;
+        return kmode[i] == 2 && hilo_c && c->opt_qkv_attn_c && c->vit.adapters[i].fold[ac->priors ? 0 : 1].wp_qcat != nullptr &&
+               qkv_attn_ok(n_seq, L, D, heads, D + 64, D + 64);
+    };
     int rln_i = 0;                  // index of the next LayerNorm-emitting residual GEMM
     bool x_is_hilo = false;         // the stream currently lives in (h, xlo, muc), not in x
     auto rln_args = [&](GemmArgs& g) {
@@ -756,7 +770,15 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         const size_t qoff = row0_last ? D : 0;
         GemmArgs g{};
         g.A = h; g.lda = D; g.out = qkv + qoff; g.ldc = 3 * D; g.M = M; g.N = 3 * D - (int)qoff; g.K = D;
-        if (fuse && kcat == 2) {      // ln_1(x + a) W^T: [x16 | e] x [W'_qkv | W'_qkv Q], the statistics are those of x + a
+        if (fuse && kcat == 2 && qa_block(i, row0_last)) {
+            QkvAttnArgs qa{};
+            qa.x16 = att; qa.lda = D + 64; qa.K = D + 64; qa.wp = c->vit.adapters[i].fold[ac->priors ? 0 : 1].wp_qcat; qa.bcs = b.bcs_qkv;
+            qa.mr = mr; qa.out = att2; qa.ldo = D + 64;
+            qa.n_seq = n_seq; qa.L = L; qa.D = D; qa.heads = heads; qa.gsz = c->opt_qkv_attn_gsz;
+            qa.a_bytes = (unsigned)(rup(M, 256) * (size_t)(D + 64) * 2);
+            ProfScope ps(c, s, HG_PROF_QKV_ATTN, n_seq, L, heads);
+            HG_HIP(launch_qkv_attn(qa, s));
+        } else if (fuse && kcat == 2) {      // ln_1(x + a) W^T: [x16 | e] x [W'_qkv | W'_qkv Q], the statistics are those of x + a
             g.A = att; g.lda = D + 64; g.K = D + 64;
             g.W = c->vit.adapters[i].fold[ac->priors ? 0 : 1].wq_cat; g.bias = b.bf_qkv; g.cs = b.cs_qkv; g.mr = mr;
             HG_HIP(gemm(c, EPI_LN_BIAS_F16, g, s));
@@ -991,7 +1013,7 @@ hg_ctx* hg_create(int device) {
                                                            {"HG_LN_FUSE", "ln_fuse"}, {"HG_ADAPTER_FUSE", "adapter_fuse"},
                                                            {"HG_ADAPTER_FOLD", "adapter_fold"}, {"HG_STREAM_HILO", "stream_hilo"},
                                                            {"HG_QKV_ATTN", "qkv_attn"}, {"HG_QKV_ATTN_MIN_SEQ", "qkv_attn_min_seq"},
-                                                           {"HG_QKV_ATTN_GSZ", "qkv_attn_gsz"}, {"HG_VAE_FUSED", "vae_fused"}, {"HG_MLP_FUSED", "mlp_fused"}};
+                                                           {"HG_QKV_ATTN_GSZ", "qkv_attn_gsz"}, {"HG_QKV_ATTN_C", "qkv_attn_c"}, {"HG_VAE_FUSED", "vae_fused"}, {"HG_MLP_FUSED", "mlp_fused"}};
     for (auto& o : init)
         if (const char* e = getenv(o.env)) (void)hg_set_option(c, o.key, atoi(e));      // (out-of-range values are ignored)
     c->err.clear();
@@ -1018,6 +1040,9 @@ int hg_set_option(hg_ctx* c, const char* key, int value) {
     } else if (k == "qkv_attn_gsz") {
         if (value < 0 || value > 6) return fail(c, HG_ERR_INVALID, "qkv_attn_gsz must be 0 .. 6 (got %d)", value);
         c->opt_qkv_attn_gsz = value;
+    } else if (k == "qkv_attn_c") {
+        if (value < 0 || value > 1) return fail(c, HG_ERR_INVALID, "qkv_attn_c must be 0 or 1 (got %d)", value);
+        c->opt_qkv_attn_c = value;
     }
     else if (k == "vae_fused") {
         if (value < 0 || value > 2) return fail(c, HG_ERR_INVALID, "vae_fused must be 0, 1 or 2 (got %d)", value);
@@ -1043,6 +1068,7 @@ int hg_get_option(hg_ctx* c, const char* key, int* value) {
     else if (k == "qkv_attn") *value = c->opt_qkv_attn;
     else if (k == "qkv_attn_min_seq") *value = c->opt_qkv_attn_min_seq;
     else if (k == "qkv_attn_gsz") *value = c->opt_qkv_attn_gsz;
+    else if (k == "qkv_attn_c") *value = c->opt_qkv_attn_c;
     else if (k == "vae_fused") *value = c->opt_vae_fused;
     else if (k == "mlp_fused") *value = c->opt_mlp_fused;
     else return fail(c, HG_ERR_INVALID, "unknown option '%s'", key);
@@ -1304,28 +1330,31 @@ int hg_test_qkv_attn(hg_ctx* c, const float* a, const float* w, const float* bia
     hipStream_t s = (hipStream_t)stream;
     HG_ON_DEVICE(c);
     const int D = heads * 64, M = n_seq * L;
+    const int K = D + ((fused & 2) ? 64 : 0);      // (bit 1: a is [M, D + 64], w [3D, D + 64] - the shape of a block with a folded adapter)
+    fused &= 1;
     const size_t Mp = rup(M, 256);
-    if (fused && !qkv_attn_ok(n_seq, L, D, heads, D)) return fail(c, HG_ERR_INVALID, "hg_test_qkv_attn: shape not eligible for the fused kernel");
-    int rc = ensure(c, c->h, Mp * D * 2);
-    if (!rc) rc = ensure(c, c->fc, (size_t)3 * D * D * 2 * 2 + (size_t)(heads / 2 + 1) * 768 * 4);
+    if (fused && !qkv_attn_ok(n_seq, L, D, heads, K, K)) return fail(c, HG_ERR_INVALID, "hg_test_qkv_attn: shape not eligible for the fused kernel");
+    int rc = ensure(c, c->h, Mp * K * 2);
+    if (!rc) rc = ensure(c, c->fc, (size_t)3 * D * K * 2 * 2 + (size_t)(heads / 2 + 1) * 768 * 4);
     if (!rc) rc = ensure(c, c->qkv, Mp * 3 * D * 2);
     if (!rc) rc = ensure(c, c->att, Mp * D * 2);
     if (!rc) rc = ensure(c, c->mr, Mp * 2 * 4);
     if (rc) return rc;
     half_t* w16 = (half_t*)c->fc.p;
-    half_t* wp = w16 + (size_t)3 * D * D;
-    float* bcs = (float*)(wp + (size_t)3 * D * D);
-    HG_HIP(launch_f32_to_f16(a, (half_t*)c->h.p, (size_t)M * D, s));
-    HG_HIP(launch_f32_to_f16(w, w16, (size_t)3 * D * D, s));
+    half_t* wp = w16 + (size_t)3 * D * K;
+    float* bcs = (float*)(wp + (size_t)3 * D * K);
+    HG_HIP(hipMemsetAsync(c->h.p, 0, Mp * K * 2, s));
+    HG_HIP(launch_f32_to_f16(a, (half_t*)c->h.p, (size_t)M * K, s));
+    HG_HIP(launch_f32_to_f16(w, w16, (size_t)3 * D * K, s));
     HG_HIP(hipMemsetAsync(c->mr.p, 0, Mp * 2 * 4, s));
     HG_HIP(hipMemcpyAsync(c->mr.p, mr, (size_t)M * 2 * 4, hipMemcpyDeviceToDevice, s));
     HG_HIP(hipMemsetAsync(c->att.p, 0, Mp * D * 2, s));
     if (fused) {
-        HG_HIP(launch_pack_qkv(w16, bias, cs, wp, bcs, D, heads, s));
+        HG_HIP(launch_pack_qkv(w16, bias, cs, wp, bcs, D, heads, s, K));
         QkvAttnArgs qa{};
-        qa.x16 = (const half_t*)c->h.p; qa.lda = D; qa.wp = wp; qa.bcs = bcs; qa.mr = (const float*)c->mr.p;
+        qa.x16 = (const half_t*)c->h.p; qa.lda = K; qa.K = K; qa.wp = wp; qa.bcs = bcs; qa.mr = (const float*)c->mr.p;
         qa.out = (half_t*)c->att.p; qa.ldo = D; qa.n_seq = n_seq; qa.L = L; qa.D = D; qa.heads = heads;
-        qa.gsz = c->opt_qkv_attn_gsz; qa.a_bytes = (unsigned)(Mp * (size_t)D * 2);
+        qa.gsz = c->opt_qkv_attn_gsz; qa.a_bytes = (unsigned)(Mp * (size_t)K * 2);
 #ifdef HG_STAMPS
         if (!(rc = ensure(c, c->cq, 256 * 8 * 16 * 8))) qa.dbg = (unsigned long long*)c->cq.p;      // read back by tools/qkv_attn_stamps.py
         else return rc;
@@ -1358,8 +1387,8 @@ int hg_test_qkv_attn(hg_ctx* c, const float* a, const float* w, const float* bia
 #endif
     } else {
         GemmArgs g{};
-        g.A = (const half_t*)c->h.p; g.lda = D; g.W = w16; g.bias = bias; g.cs = cs; g.mr = (const float*)c->mr.p;
-        g.out = c->qkv.p; g.ldc = 3 * D; g.M = M; g.N = 3 * D; g.K = D;
+        g.A = (const half_t*)c->h.p; g.lda = K; g.W = w16; g.bias = bias; g.cs = cs; g.mr = (const float*)c->mr.p;
+        g.out = c->qkv.p; g.ldc = 3 * D; g.M = M; g.N = 3 * D; g.K = K;
         if (!gemm_ln_ok(EPI_LN_BIAS_F16, g)) return fail(c, HG_ERR_INVALID, "hg_test_qkv_attn: shape not eligible for the folded GEMM");
         HG_HIP(gemm(c, EPI_LN_BIAS_F16, g, s));
         HG_HIP(attention(c, (const half_t*)c->qkv.p, (half_t*)c->att.p, n_seq, L, heads, false, s));

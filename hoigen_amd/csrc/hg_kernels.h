@@ -122,17 +122,18 @@ struct QkvAttnArgs {
     half_t* out = nullptr;
     int ldo = 0;                 // 0 = D
     int n_seq = 0, L = 0, D = 0, heads = 0;
+    int K = 0;                   // row length of x16 / of W that is summed over (0 = D; D + 64 with the adapter's e columns behind x16)
     unsigned a_bytes = 0;        // bytes readable behind x16 (0: rows padded to a multiple of 256)
     int gsz = 0;                 // head pairs per XCD group (0 = all: the pairs of a sequence side by side)
     unsigned long long* dbg = nullptr;   // diagnostics: s_memtime totals per wave (HG_STAMPS build), normally null
 };
-// 192 < L <= 208, D = 64 * heads, heads even, D / 64 a multiple of 3 (ViT-B/16: L = 197, D = 768)
-bool qkv_attn_ok(int n_seq, int L, int D, int heads, int lda);
+// 192 < L <= 208, D = 64 * heads, heads even, D / 64 a multiple of 3 (ViT-B/16: L = 197, D = 768); K / 64 = 3 m or 3 m + 1
+bool qkv_attn_ok(int n_seq, int L, int D, int heads, int lda, int K = 0);
 // speed only: is the last round of (sequence, head pair) items filled well enough (n_cu <= 0: 256)
 bool qkv_attn_pays(int n_seq, int heads, int n_cu);
-// W [3D, D] fp16 (LayerNorm-folded), bias / cs [3D] -> Wp [3D * D] fp16 in fragment order, bcs [heads / 2][768] fp32
+// W [3D, K] fp16 (LayerNorm-folded), bias / cs [3D] -> Wp [3D * K] fp16 in fragment order, bcs [heads / 2][768] fp32 (null: not written)
 hipError_t launch_pack_qkv(const half_t* W, const float* bias, const float* cs, half_t* Wp, float* bcs, int D, int heads,
-                           hipStream_t s);
+                           hipStream_t s, int K = 0);
 hipError_t launch_qkv_attn(const QkvAttnArgs& a, hipStream_t s);
 
 // ---- CoOp-VAE as one kernel (hg_vae_fused.hip): Encoder -> reparameterise -> Generator with both hidden layers and z on chip --------

@@ -248,6 +248,8 @@ int hg_vae_loss(hg_ctx*, const float* recon, const float* x, const float* mean, 
  *                      of its (sequence, head pair) items is well filled: speed only).  Bit-identical results either way.
  *   "qkv_attn_min_seq" [HG_QKV_ATTN_MIN_SEQ] ... from this many sequences per call on (default 32)
  *   "qkv_attn_gsz"    [HG_QKV_ATTN_GSZ]    head pairs per XCD group of that kernel (0 = all six side by side; speed only)
+ *   "qkv_attn_c"      [HG_QKV_ATTN_C]      1 (default): also in the blocks whose instance adapter is folded into in_proj (variant C on the
+ *                      hi / lo stream: the same kernel summing over D + 64 columns); 0: those blocks keep the two kernels.  Bit-identical.
  *   "vae_fused"       [HG_VAE_FUSED]       1: hg_vae_forward / hg_generator run Encoder -> reparameterise -> Generator as ONE kernel
  *                      (hoigen_amd/csrc/hg_vae_fused.hip: both hidden layers and z stay on chip; dim 512, hidden widths multiples of 32
  *                      up to 4096) for the leading rows that fill whole rounds of its 128-row work items over the CUs, the GEMM path for
@@ -315,8 +317,9 @@ int hg_test_attention(hg_ctx*, const float* qkv, const float* q0, const int32_t*
 /* Test hook for the fused in_proj + attention kernel (hoigen_amd/csrc/hg_qkv_attn.hip; the reference ops it replaces:
  * clipnet/model.py:171,181-183).  a [n_seq*L, D] fp32 (rounded to fp16 inside: the centred copy of the stream), w [3D, D] the
  * LayerNorm-folded in_proj weight, bias / cs [3D], mr [n_seq*L, 2] = (mean - centre, rstd), D = 64 * heads; out [n_seq*L, D]
- * fp32 = the attention output.  fused != 0: the one kernel (192 < L <= 208, heads even, D / 64 a multiple of 3);
- * fused == 0: the folded GEMM followed by hg_test_attention's kernel - the two must agree bit for bit. */
+ * fp32 = the attention output.  fused bit 0 set: the one kernel (192 < L <= 208, heads even, D / 64 a multiple of 3);
+ * clear: the folded GEMM followed by hg_test_attention's kernel - the two must agree bit for bit.  fused bit 1 set: a is
+ * [n_seq*L, D + 64] and w [3D, D + 64], the summed length of a block whose adapter is folded into in_proj (variant C). */
 int hg_test_qkv_attn(hg_ctx*, const float* a, const float* w, const float* bias, const float* cs, const float* mr, int n_seq,
                      int L, int heads, int fused, float* out, void* stream);
 

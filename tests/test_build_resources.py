@@ -62,24 +62,27 @@ def test_no_kernel_spills_registers_or_uses_scratch():
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_fused_kernel_k_loop_is_scratch_free():
-    """The sequence-tile K loop (hg_seq_kloop_run.inc inside qkv_attn_kernel) keeps every DMA in flight behind counted
-    s_waitcnt vmcnt(6): between the first and the last of them the assembly must hold no scratch access, no vmcnt(0) and all
-    468 = 6 x 78 MFMAs of its three K-tile kinds x two phases."""
+    """The sequence-tile K loop (hg_seq_kloop_run.inc inside both instances of the fused in_proj + attention kernel:
+    qkv_attn_kernel for 3 m K-tiles, qkv_attn_kernel_k1 for 3 m + 1) keeps every DMA in flight behind counted s_waitcnt vmcnt(6):
+    between the first and the last of them the assembly must hold no scratch access, no vmcnt(0), and the kernel all 78 MFMAs of
+    each of its K-tile bodies x two phases (six bodies = 468; seven = 546 with the extra tail tile of the 3 m + 1 schedule)."""
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "qa.s")
         r = subprocess.run([HIPCC, "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-S", "--cuda-device-only",
                             os.path.join(CSRC, "hg_qkv_attn.hip"), "-o", out], capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
         lines = open(out).read().split("\n")
-    start = next(i for i, l in enumerate(lines) if "qkv_attn_kernel" in l and l.startswith("_ZN") and ":" in l)
-    end = next(i for i in range(start, len(lines)) if ".end_amdhsa_kernel" in lines[i] or ".Lfunc_end" in lines[i])
-    body = lines[start:end]
-    w6 = [i for i, l in enumerate(body) if "s_waitcnt vmcnt(6)" in l]
-    assert len(w6) >= 12, "the counted waits of the K loop were not found"
-    loop = body[w6[0]:w6[-1] + 1]
-    assert not [l for l in loop if "scratch_" in l], "scratch access inside the K loop"
-    assert not [l for l in loop if "s_waitcnt vmcnt(0)" in l], "vmcnt(0) inside the K loop"
-    assert sum("v_mfma_f32_16x16x32_f16" in l for l in body) == 468
+    starts = [i for i, l in enumerate(lines) if "qkv_attn_kernel" in l and l.startswith("_ZN") and ":" in l]
+    assert len(starts) == 2, "expected the two instances of the fused kernel"
+    for start, mfmas in zip(starts, (468, 546)):
+        end = next(i for i in range(start, len(lines)) if ".end_amdhsa_kernel" in lines[i] or ".Lfunc_end" in lines[i])
+        body = lines[start:end]
+        w6 = [i for i, l in enumerate(body) if "s_waitcnt vmcnt(6)" in l]
+        assert len(w6) >= 12, "the counted waits of the K loop were not found"
+        loop = body[w6[0]:w6[-1] + 1]
+        assert not [l for l in loop if "scratch_" in l], "scratch access inside the K loop"
+        assert not [l for l in loop if "s_waitcnt vmcnt(0)" in l], "vmcnt(0) inside the K loop"
+        assert sum("v_mfma_f32_16x16x32_f16" in l for l in body) == mfmas
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")

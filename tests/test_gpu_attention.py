@@ -88,11 +88,12 @@ def test_one_row_variant_is_the_full_kernels_row(ctx, n_seq, L, heads, causal):
 
 
 # ---- in_proj + attention as ONE kernel (hg_qkv_attn.hip): q, k, v never leave the chip -------------------------------------
-def _qkv_attn_operands(n_seq, L, heads, seed):
+def _qkv_attn_operands(n_seq, L, heads, seed, extra=0):
     D = heads * 64
+    K = D + extra                                                             # (extra = 64: [x16 | e] of a block with a folded adapter)
     g = torch.Generator(device="cuda").manual_seed(seed)
-    a = torch.randn(n_seq * L, D, device="cuda", generator=g)                 # centred fp16 copy of the stream
-    w = torch.randn(3 * D, D, device="cuda", generator=g) * D ** -0.5         # LayerNorm-folded in_proj weight
+    a = torch.randn(n_seq * L, K, device="cuda", generator=g)                 # centred fp16 copy of the stream
+    w = torch.randn(3 * D, K, device="cuda", generator=g) * D ** -0.5         # LayerNorm-folded in_proj weight
     bias = torch.randn(3 * D, device="cuda", generator=g) * 0.3
     cs = w.half().float().sum(1)
     mr = torch.stack([torch.randn(n_seq * L, device="cuda", generator=g) * 0.05,
@@ -129,6 +130,29 @@ def test_fused_qkv_attention_equals_gemm_then_attention(ctx, n_seq, L, heads):
     qkv = ((a.half().float() @ w.half().float().t() - mr[:, :1] * cs[None]) * mr[:, 1:] + bias[None])
     ref = ref_attention(qkv, n_seq, L, heads, False)
     assert (got - ref).abs().max().item() <= 3e-3 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("n_seq,L,heads", [(3, 197, 12), (41, 197, 12), (128, 197, 12), (300, 197, 12), (5, 193, 12), (4, 208, 12),
+                                           (7, 200, 6)])
+def test_fused_qkv_attention_over_d_plus_64_columns(ctx, n_seq, L, heads):
+    """The block with a folded instance adapter (variant C): in_proj sums over D + 64 columns = 13 (7 for D = 384) K-tiles, the
+    3 m + 1 schedule of the K loop (hg_seq_kloop_run.inc, second kernel instance).  Same evidence as above: bit-identical to the
+    K = D + 64 GEMM followed by attention, repeated launches agree, and fp32 PyTorch."""
+    ops = _qkv_attn_operands(n_seq, L, heads, 2000 * L + 10 * n_seq + heads, extra=64)
+    got = run_qkv_attn(ctx, ops, n_seq, L, heads, 3)
+    if heads * 192 % 256 == 0:
+        want = run_qkv_attn(ctx, ops, n_seq, L, heads, 2)
+        assert torch.equal(got, want), f"max abs diff {(got - want).abs().max().item():.3e}"
+    for _ in range(3):
+        assert torch.equal(got, run_qkv_attn(ctx, ops, n_seq, L, heads, 3))
+    a, w, bias, cs, mr = ops
+    qkv = ((a.half().float() @ w.half().float().t() - mr[:, :1] * cs[None]) * mr[:, 1:] + bias[None])
+    ref = ref_attention(qkv, n_seq, L, heads, False)
+    assert (got - ref).abs().max().item() <= 3e-3 * ref.abs().max().item()
+    # the D-column kernel instance still runs unharmed beside it
+    ops0 = _qkv_attn_operands(n_seq, L, heads, 5)
+    if heads * 192 % 256 == 0:
+        assert torch.equal(run_qkv_attn(ctx, ops0, n_seq, L, heads, 1), run_qkv_attn(ctx, ops0, n_seq, L, heads, 0))
 
 
 def test_fused_qkv_attention_under_xcd_group_sizes(ctx):

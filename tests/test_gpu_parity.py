@@ -723,3 +723,33 @@ def test_variant_c_on_the_hi_lo_stream_vs_reference():
         m.visual.set_option("stream_hilo", 1)
     assert not torch.equal(outs[1][0], outs[0][0]), "the switch did not change the executed path"
     check(outs[1][0], outs[0][0].cpu().numpy(), what="variant C hi / lo stream vs fp32 stream (global)")
+
+
+def test_variant_c_in_proj_and_attention_as_one_kernel_is_bit_identical():
+    """Variant C's blocks sum in_proj over [x16 | e] (D + 64 = 832 columns): the fused in_proj + attention kernel's second instance
+    (13 K-tiles) runs them by default (option qkv_attn_c); switching it off gives the K = 832 GEMM and the attention kernel - the same
+    bits, with priors and without, and the launches of the step really change."""
+    from hoigen_amd import _lib
+    sd = synth.to_torch(synth.clip_state_dict(synth.VIT_B16, 0))
+    sd.update(synth.to_torch(synth.adapter_state_dict(synth.VIT_B16, 1)))
+    m = build_model(sd, use_adapter=True).to(dev())
+    torch.manual_seed(4)
+    img = torch.randn(40, 3, 224, 224, device=dev())
+    pri = torch.randn(40, 14, 64, device=dev())
+    mask = torch.zeros(40, 14, dtype=torch.bool, device=dev())
+    mask[::3, 9:] = True
+    outs, fused_launches = {}, {}
+    try:
+        for mode in (1, 0):
+            m.visual.set_option("qkv_attn_c", mode)
+            m.visual(img, (pri, mask))      # (weights folded and packed outside the profiled call)
+            (gl, lo), recs = _lib.profile(m.visual._ctx.handle, _lib.HG_PROF_ALL, 512, lambda: m.visual(img, (pri, mask)))
+            gn, ln_ = m.visual(img, None)
+            outs[mode] = (gl, lo, gn, ln_)
+            fused_launches[mode] = sum(1 for r in recs if r[0] == _lib.HG_PROF_QKV_ATTN)
+    finally:
+        m.visual.set_option("qkv_attn_c", 1)
+    assert fused_launches[1] == 12 and fused_launches[0] == 0, fused_launches
+    for a, b in zip(outs[1], outs[0]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+
