@@ -753,3 +753,31 @@ def test_variant_c_in_proj_and_attention_as_one_kernel_is_bit_identical():
     for a, b in zip(outs[1], outs[0]):
         assert torch.isfinite(a).all() and torch.equal(a, b)
 
+
+def test_variant_c_non_finite_crop_does_not_poison_its_neighbours():
+    """The same row independence on the detector's call (variant C: adapters folded into the GEMMs, hi / lo stream, in_proj + attention
+    as one kernel over D + 64 columns, CLIP_models_adapter_prior2.py:489-506 mixes no crops either): one NaN crop (image and priors) in
+    a batch of 64 leaves the others finite and bit-equal to the clean run; a clean batch of 40 behind it is clean."""
+    d = dev()
+    sd = synth.to_torch(synth.clip_state_dict(synth.VIT_B16, 0))
+    sd.update(synth.to_torch(synth.adapter_state_dict(synth.VIT_B16, 1)))
+    m = build_model(sd, use_adapter=True).to(d)
+    torch.manual_seed(6)
+    img = torch.randn(64, 3, 224, 224, device=d)
+    pri = torch.randn(64, 14, 64, device=d)
+    mask = torch.zeros(64, 14, dtype=torch.bool, device=d)
+    mask[:, 11:] = True
+    clean_g, clean_l = m.visual(img, (pri, mask))
+    bad_i, bad_p = img.clone(), pri.clone()
+    bad_i[40] = float("nan")
+    bad_p[40] = float("nan")
+    g, l = m.visual(bad_i, (bad_p, mask))
+    keep = torch.ones(64, dtype=torch.bool, device=d)
+    keep[40] = False
+    assert not torch.isfinite(g[40]).all(), "the NaN crop itself must not come out finite"
+    assert torch.isfinite(g[keep]).all() and torch.isfinite(l[keep]).all(), "a NaN crop leaked into its neighbours"
+    assert torch.equal(g[keep], clean_g[keep]) and torch.equal(l[keep], clean_l[keep])
+    g2, l2 = m.visual(img[:40], (pri[:40], mask[:40]))      # workspace rows behind crop 39 still hold the NaN crop's activations
+    assert torch.isfinite(g2).all() and torch.isfinite(l2).all()
+    assert torch.equal(g2, clean_g[:40]) and torch.equal(l2, clean_l[:40])
+
