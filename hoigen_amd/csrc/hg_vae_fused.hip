@@ -106,6 +106,10 @@ struct VaeFusedDev {
     unsigned long long* dbg;
 };
 
+// MSET: the passes this instantiation holds - 0 = Encoder (+ Generator): modes 0 and 1, 2 = Generator only, 3 = MLP block.  One kernel
+// with every pass kind carried the Encoder epilogues' 36 spilled dwords (and their 68 bytes of private segment per lane) into the
+// Generator-only and MLP launches, which are the ones the default dispatch uses.
+template <int MSET>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void vae_fused_kernel(const VaeFusedDev p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -402,12 +406,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
         VF_STAMP_E(tk_x);
-        if (p.mode == 3) run_pass(K3{}, p.nbg, p.b0g);
+        if constexpr (MSET == 3) run_pass(K3{}, p.nbg, p.b0g);
+        else if constexpr (MSET == 2) run_pass(K2{}, p.nbg, p.b0g);
         else {
-            if (p.mode != 2) {
-                run_pass(K0{}, p.nbe, p.b0e);
-                run_pass(K1{}, p.nbe, p.b0e);
-            }
+            run_pass(K0{}, p.nbe, p.b0e);
+            run_pass(K1{}, p.nbe, p.b0e);
             if (p.mode != 1) run_pass(K2{}, p.nbg, p.b0g);
         }
     }
@@ -507,9 +510,11 @@ hipError_t launch_vae_fused(const VaeFusedArgs& a, hipStream_t s) {
     const int dev_i = current_device_index();
     if (!attr_set_d[dev_i]) {
         n_cu_d[dev_i] = 256;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vae_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024);
-        if (e != hipSuccess) return e;
+        for (const void* f : {reinterpret_cast<const void*>(&vae_fused_kernel<0>), reinterpret_cast<const void*>(&vae_fused_kernel<2>),
+                              reinterpret_cast<const void*>(&vae_fused_kernel<3>)}) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu_d[dev_i] = prop.multiProcessorCount;
@@ -523,7 +528,9 @@ hipError_t launch_vae_fused(const VaeFusedArgs& a, hipStream_t s) {
     d.dbg = dbg;
     if (dbg) (void)hipMemsetAsync(dbg, 0, (size_t)1024 * 4 * 8 * 8, s);
 #endif
-    hipLaunchKernelGGL(vae_fused_kernel, dim3(grid), dim3(256), VF_LDS, s, d);
+    if (a.mode == 3) hipLaunchKernelGGL(vae_fused_kernel<3>, dim3(grid), dim3(256), VF_LDS, s, d);
+    else if (a.mode == 2) hipLaunchKernelGGL(vae_fused_kernel<2>, dim3(grid), dim3(256), VF_LDS, s, d);
+    else hipLaunchKernelGGL(vae_fused_kernel<0>, dim3(grid), dim3(256), VF_LDS, s, d);
 #ifdef HG_STAMPS
     if (dbg && getenv("HG_VF_STAMPS")) {
         (void)hipStreamSynchronize(s);

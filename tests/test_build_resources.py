@@ -41,15 +41,17 @@ def test_no_kernel_spills_registers_or_uses_scratch():
     assert len(kernels) >= 60, f"only {len(kernels)} kernels seen: the remarks were not parsed"
     # SGPR "spills" are v_writelane moves into spare VGPR lanes, not memory: tolerated only in the two fp32 fallback kernels of
     # the adapter (weights held in scalar registers by design: hg_adapter.hip), which no batch-256 path runs
-    sgpr_ok = ("adapter_kv_kernel", "adapter_decoder_kernel", "qkv_attn_kernel", "vae_fused_kernel")
+    sgpr_ok = ("adapter_kv_kernel", "adapter_decoder_kernel", "qkv_attn_kernel", "vae_fused_kernelILi0E")
     # (qkv_attn_kernel, hg_qkv_attn.hip, runs its K loop on 156 accumulator + 48 fragment registers and its attention phases beside
     # 78 registers of parked fp16 results: it used to park a handful of per-item values in scratch across the K loop; values the
     # allocator would keep live across the loop - a hoisted lane id of __shfl_xor, a hoisted `wave < 2`, a constant pair, the zero high
     # half of a 64-bit store offset - are now made where they are used.  No VGPR spill, no scratch: nothing is tolerated here.)
-    # vae_fused_kernel (hg_vae_fused.hip) holds 256 accumulator + 128 operand registers through its pass loops; at the joins between
-    # its three pass epilogues the allocator parks one accumulator block (16 + 4 dwords) in scratch for the duration of an epilogue
-    # (three per 128-row item of ~0.3 ms; 36 dwords in all with the MLP-block pass).  Its pass LOOPS must be free of scratch and vmcnt(0): test_vae_fused_pass_loops_are_scratch_free.
-    few_ok = {"vae_fused_kernel": 40}
+    # vae_fused_kernel<0> (hg_vae_fused.hip: the instance that holds the Encoder passes, options vae_fused = 2 only) keeps 256 accumulator
+    # + 128 operand registers through its pass loops; at the joins between its three pass epilogues the allocator parks one accumulator
+    # block in scratch for the duration of an epilogue (three per 128-row item of ~0.3 ms; 30 dwords).  Its pass LOOPS must be free
+    # of scratch and vmcnt(0): test_vae_fused_pass_loops_are_scratch_free.  The Generator-only and MLP-block instances (<2>, <3>: what the
+    # default dispatch launches) spill nothing and fall under the rule for every other kernel.
+    few_ok = {"vae_fused_kernelILi0E": 40}
     def tolerated(r):
         f, n, k, v = r
         if k == "SGPRs Spill" and any(x in n for x in sgpr_ok):
@@ -87,7 +89,7 @@ def test_fused_kernel_k_loop_is_scratch_free():
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_vae_fused_pass_loops_are_scratch_free():
-    """The four pass loops of vae_fused_kernel (two iterations of 64 MFMAs per trip) keep six ring stages of LDS-DMA in flight behind
+    """The pass loops of the three vae_fused_kernel instances (two iterations of 64 MFMAs per trip) keep six ring stages of LDS-DMA in flight behind
     counted s_waitcnt vmcnt(20): a scratch reload inside them waits for vmcnt(0) and drains the ring once per iteration (measured:
     4 750 instead of 2 100 cycles per iteration).  Every innermost loop that holds MFMAs must hold exactly 128 of them, 8 barriers,
     no scratch access, no vmcnt(0), and no AGPR<->VGPR copies (the layer-1 accumulators are VGPR-form inline asm for that reason)."""
@@ -97,14 +99,16 @@ def test_vae_fused_pass_loops_are_scratch_free():
                             os.path.join(CSRC, "hg_vae_fused.hip"), "-o", out], capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
         lines = open(out).read().split("\n")
-    labels = {m.group(1): i for i, l in enumerate(lines) if (m := re.match(r"^(\.LBB0_\d+):", l))}
+    labels = {m.group(1): i for i, l in enumerate(lines) if (m := re.match(r"^(\.LBB\d+_\d+):", l))}
     loops = []
     for i, l in enumerate(lines):
-        m = re.search(r"s_c?branch\w*\s+(\.LBB0_\d+)", l)
+        m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", l)
         if m and m.group(1) in labels and labels[m.group(1)] < i:
             loops.append((labels[m.group(1)], i))
-    inner = [(a, b) for a, b in loops if sum("v_mfma" in x for x in lines[a:b + 1]) == 128]
-    assert len(inner) == 4, f"expected the four pass loops (Encoder x 2, Generator, MLP block), found {len(inner)}"
+    with_128 = [(a, b) for a, b in loops if sum("v_mfma" in x for x in lines[a:b + 1]) == 128]
+    # (the item loop of a one-pass instance holds the same 128 MFMAs as its pass loop: innermost loops only)
+    inner = [(a, b) for a, b in with_128 if not any((a2, b2) != (a, b) and a <= a2 and b2 <= b for a2, b2 in with_128)]
+    assert len(inner) == 5, f"expected five pass loops (instance <0>: Encoder x 2 + Generator, <2>: Generator, <3>: MLP block), found {len(inner)}"
     for a, b in inner:
         body = lines[a:b + 1]
         assert sum("s_barrier" in x for x in body) == 8
