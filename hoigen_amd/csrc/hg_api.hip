@@ -148,6 +148,7 @@ struct hg_ctx {
     int opt_qkv_attn_min_seq = 32;   // ... from this many sequences per call on, and where its last round of items is filled well
                                      // enough (qkv_attn_pays; qkv_attn = 2: wherever the shapes allow)
     int opt_qkv_attn_gsz = 0;    // head pairs per XCD group of that kernel (0 = all)
+    int opt_text_ln_fold = 0;    // text tower: LayerNorm folded into its GEMMs like the vision tower's (0: separate LayerNorm kernels)
     int opt_qkv_attn_c = 1;      // ... also in the blocks that carry a folded adapter (variant C on the hi / lo stream: K = D + 64)
     int opt_mlp_fused = 0;       // blocks of width 512 (text tower): 1 = c_fc -> QuickGELU -> c_proj -> residual as ONE kernel for the rows that
                                  // fill whole rounds of 128-row items (hg_vae_fused.hip, mode 3), 2 = every row, 0 (default) = the two GEMMs:
@@ -1013,7 +1014,7 @@ hg_ctx* hg_create(int device) {
                                                            {"HG_LN_FUSE", "ln_fuse"}, {"HG_ADAPTER_FUSE", "adapter_fuse"},
                                                            {"HG_ADAPTER_FOLD", "adapter_fold"}, {"HG_STREAM_HILO", "stream_hilo"},
                                                            {"HG_QKV_ATTN", "qkv_attn"}, {"HG_QKV_ATTN_MIN_SEQ", "qkv_attn_min_seq"},
-                                                           {"HG_QKV_ATTN_GSZ", "qkv_attn_gsz"}, {"HG_QKV_ATTN_C", "qkv_attn_c"}, {"HG_VAE_FUSED", "vae_fused"}, {"HG_MLP_FUSED", "mlp_fused"}};
+                                                           {"HG_QKV_ATTN_GSZ", "qkv_attn_gsz"}, {"HG_QKV_ATTN_C", "qkv_attn_c"}, {"HG_TEXT_LN_FOLD", "text_ln_fold"}, {"HG_VAE_FUSED", "vae_fused"}, {"HG_MLP_FUSED", "mlp_fused"}};
     for (auto& o : init)
         if (const char* e = getenv(o.env)) (void)hg_set_option(c, o.key, atoi(e));      // (out-of-range values are ignored)
     c->err.clear();
@@ -1040,6 +1041,9 @@ int hg_set_option(hg_ctx* c, const char* key, int value) {
     } else if (k == "qkv_attn_gsz") {
         if (value < 0 || value > 6) return fail(c, HG_ERR_INVALID, "qkv_attn_gsz must be 0 .. 6 (got %d)", value);
         c->opt_qkv_attn_gsz = value;
+    } else if (k == "text_ln_fold") {
+        if (value < 0 || value > 1) return fail(c, HG_ERR_INVALID, "text_ln_fold must be 0 or 1 (got %d)", value);
+        c->opt_text_ln_fold = value;
     } else if (k == "qkv_attn_c") {
         if (value < 0 || value > 1) return fail(c, HG_ERR_INVALID, "qkv_attn_c must be 0 or 1 (got %d)", value);
         c->opt_qkv_attn_c = value;
@@ -1069,6 +1073,7 @@ int hg_get_option(hg_ctx* c, const char* key, int* value) {
     else if (k == "qkv_attn_min_seq") *value = c->opt_qkv_attn_min_seq;
     else if (k == "qkv_attn_gsz") *value = c->opt_qkv_attn_gsz;
     else if (k == "qkv_attn_c") *value = c->opt_qkv_attn_c;
+    else if (k == "text_ln_fold") *value = c->opt_text_ln_fold;
     else if (k == "vae_fused") *value = c->opt_vae_fused;
     else if (k == "mlp_fused") *value = c->opt_mlp_fused;
     else return fail(c, HG_ERR_INVALID, "unknown option '%s'", key);
@@ -1509,7 +1514,7 @@ int hg_load_text(hg_ctx* c, const hg_text_weights* w) {
     keep_first(rc, as_f32(c, t.owned, w->ln_final_bias, D, &t.lnf_b, "ln_final.bias"));
     keep_first(rc, as_f16_T(c, t.owned, w->text_projection, D, t.E, &t.w_projT, "text_projection"));
     if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
-    rc = load_blocks(c, t.owned, w->blocks, t.layers, D, t.blocks, false);
+    rc = load_blocks(c, t.owned, w->blocks, t.layers, D, t.blocks, true);      // (folded operands too: option text_ln_fold)
     if (rc) return rc;
     HG_HIP(hipDeviceSynchronize());
     t.loaded = true;
@@ -1843,10 +1848,10 @@ static int text_chunk_prompts(const hg_ctx* c, int n_prompts, int Leff) {
 static int text_tail(hg_ctx* c, int Tc, int Leff, const int32_t* eot, float* out, hipStream_t s) {
     Text& t = c->text;
     const int D = t.D, E = t.E;
-    // the text tower keeps the separate LayerNorm: folding moved its parity error from 6.5e-4 to 7.4e-4 (worst
-    // prompt 9.0e-4) of the 1e-3 budget, for no measurable time gain at these sizes
+    // the text tower keeps the separate LayerNorm by default: folding (option text_ln_fold) moves its parity error from 6.5e-4 to
+    // 7.6e-4 (worst prompt 9.6e-4) of the 1e-3 budget; since the hi / lo stream it does buy time (600 x 77 tokens: 5.2 -> 4.6 ms)
     const float* rows = nullptr;      // dense EOT rows when the last block ran on them only
-    int rc = run_blocks(c, t.blocks, Tc, Leff, D, t.heads, true, s, nullptr, 0, nullptr, false, &rows, eot);
+    int rc = run_blocks(c, t.blocks, Tc, Leff, D, t.heads, true, s, nullptr, 0, nullptr, c->opt_text_ln_fold != 0, &rows, eot);
     if (rc) return rc;
     half_t* h16 = (half_t*)c->head16.p;
     // ln_final, select the EOT row, @ text_projection (clipnet/model.py:346-350); LN is row-wise so
