@@ -333,7 +333,23 @@ def generation(model, dev):
     ms_text = timed(lambda: sampler.text_encoder(prompts, toks), 5)
     executed = prompts.shape[0] * text_flops(Lt, last_block_one_row=True)
     nominal = prompts.shape[0] * text_flops(77)
-    return {"workload": "generation loop of main_tip_finetune.py:759-824: 100 iterations x (hoi, human, object) x 600 targets -> 180 000 "
+    # the same loop with the text tower's LayerNorms folded (option text_ln_fold, off by default: parity margin, see config3)
+    model.set_option("text_ln_fold", 1)
+    try:
+        sampler.sample(iterations=bi, generator=gen, batch_iters=bi)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        feat2, _ = sampler.sample(iterations=iters, generator=gen, batch_iters=bi)
+        torch.cuda.synchronize(dev)
+        dt2 = time.perf_counter() - t0
+        ms_text2 = timed(lambda: sampler.text_encoder(prompts, toks), 5)
+        assert bool(torch.isfinite(feat2).all())
+    finally:
+        model.set_option("text_ln_fold", 0)
+    fold = {"option": "text_ln_fold = 1 (not the default)", "ms_per_iteration": round(dt2 / iters * 1e3, 4),
+            "features_per_s": round(feat2.shape[0] / dt2, 0), "text_tower_ms": round(ms_text2, 4),
+            "text_tower_frac_executed": round(executed / ms_text2 / 1e9 / MFMA_PEAK_TFLOPS, 4)}
+    return {"with_text_ln_fold": fold, "workload": "generation loop of main_tip_finetune.py:759-824: 100 iterations x (hoi, human, object) x 600 targets -> 180 000 "
                         "features [z -> Generator -> PromptLearner -> TextEncoder -> L2 -> mlp_net], seeded synthetic branch weights, "
                         f"{bi} iterations per pass through the kernels",
             "iterations": iters, "features": int(feat.shape[0]), "total_ms": round(dt * 1e3, 2),
