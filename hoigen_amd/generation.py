@@ -36,10 +36,14 @@ class Branch:
 
 
 class FeatureSampler:
-    def __init__(self, clip_model: CLIP, branches: "Dict[str, Branch]"):
+    def __init__(self, clip_model: CLIP, branches: "Dict[str, Branch]", fold_text_layernorm: bool = False):
+        """``fold_text_layernorm``: run the text tower with its LayerNorms folded into the GEMMs while sampling (library option
+        ``text_ln_fold``, include/hoigen_amd.h: 11 % faster - 2.95 -> 2.62 ms per iteration of the HICO loop - for 1e-4 of the 1e-3
+        parity tolerance against the reference; off by default like the option itself)."""
         self.clip = clip_model
         self.branches = branches
         self.text_encoder = vae.TextEncoder(clip_model)
+        self.fold_text_layernorm = bool(fold_text_layernorm)
 
     def _tokens_run(self) -> int:
         """max(EOT) + 1 over every class of every branch: the tokens the truncated text tower reads (clipnet/model.py:350 selects the
@@ -109,6 +113,8 @@ class FeatureSampler:
         feats: "Dict[str, List[torch.Tensor]]" = {k: [] for k in self.branches}
         saved = {k: b.target for k, b in self.branches.items()}
         done = 0
+        if self.fold_text_layernorm:
+            self.clip.set_option("text_ln_fold", 1)
         try:
             while done < iterations:
                 k_it = min(max(1, batch_iters), iterations - done)
@@ -123,6 +129,8 @@ class FeatureSampler:
         finally:
             for k, b in self.branches.items():
                 b.target = saved[k]
+            if self.fold_text_layernorm:
+                self.clip.set_option("text_ln_fold", 0)
         gen_feature = torch.cat([torch.cat(feats[k], dim=0) for k in self.branches], dim=0)
         gen_target = torch.cat([b.target.to(dev).repeat(iterations) for b in self.branches.values()], dim=0)
         return gen_feature, gen_target

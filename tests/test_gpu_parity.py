@@ -809,3 +809,23 @@ def test_text_tower_with_folded_layernorm_vs_reference(fullA, g0):
     assert torch.equal(fullA.encode_text(ids["hoi600"]).float(), base)
     fullA.truncate_text = True
 
+
+def test_feature_sampler_with_folded_text_layernorm(fullA, g0):
+    """FeatureSampler(fold_text_layernorm=True) runs the HICO loop with option text_ln_fold for the duration of sample() and puts the
+    default back: same latents -> features within the tolerance of the default path's, option off again afterwards."""
+    from hoigen_amd.generation import hico_sampler
+    s = hico_sampler(fullA, g0["_classnames"])
+    gen = torch.Generator(device=dev()).manual_seed(11)
+    base, tgt = s.sample(iterations=2, generator=gen, batch_iters=2)
+    s.fold_text_layernorm = True
+    gen = torch.Generator(device=dev()).manual_seed(11)
+    fold, tgt2 = s.sample(iterations=2, generator=gen, batch_iters=2)
+    assert torch.equal(tgt, tgt2) and base.shape == (2 * 1800, 512)
+    assert not torch.equal(base, fold), "the flag did not change the executed path"
+    # (two realisations of the fp16 roundings of 12 blocks + mlp_net, each within 1e-3 of the reference's: 9.2e-4 apart, worst row 1.3e-3)
+    check(fold, base.cpu().numpy(), tol=2e-3, what="generated features, folded text LayerNorm vs default")
+    s.fold_text_layernorm = False
+    gen = torch.Generator(device=dev()).manual_seed(11)
+    again, _ = s.sample(iterations=2, generator=gen, batch_iters=2)
+    assert torch.equal(again, base), "the default path did not come back"
+
