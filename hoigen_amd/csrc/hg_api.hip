@@ -39,6 +39,8 @@ struct BlockW {
     // b' = b + W beta;  LN(x) W^T + b = rstd * (x16 W'^T - mean * cs) + b'
     half_t *wf_qkv, *wf_fc;
     float *cs_qkv, *bf_qkv, *cs_fc, *bf_fc;
+    // column sums sum_k gamma[k] W[n][k] for the form that keeps the LayerNorm weight in the activation copy and W unrounded (text tower)
+    float *csg_qkv, *csg_fc;
     // wf_qkv / bf_qkv / cs_qkv once more in the order the fused in_proj + attention kernel streams them (hg_qkv_attn.hip:
     // MFMA fragments per head pair); null when the width does not qualify
     half_t* wp_qkv;
@@ -131,6 +133,7 @@ struct hg_ctx {
     Cache cache[HG_MAX_CACHE_SLOTS];
     // workspace (grow-only)
     Buf x, h, qkv, att, fc, head16, tok32, small, i32, ad32, ad16, adkv, mr, mu, muc, stats, pre, pretab, cx, ca, ch, cf, cq;
+    Buf hg;              // folded path with the LayerNorm weight in the activation copy h (text tower): the stream's unscaled hi half, fragment order
     Buf att2;            // variant C with the stream as centre + hi + lo: the out-proj operand [att | e] beside the in_proj one [x16 | e]
     Buf zpark;           // hg_vae_fused.hip: the encoder's first z half as fp16 fragments, per wave
     Buf xlo;             // low half of the residual stream while it is held as centre + hi + lo (GemmArgs::hl)
@@ -148,7 +151,9 @@ struct hg_ctx {
     int opt_qkv_attn_min_seq = 32;   // ... from this many sequences per call on, and where its last round of items is filled well
                                      // enough (qkv_attn_pays; qkv_attn = 2: wherever the shapes allow)
     int opt_qkv_attn_gsz = 0;    // head pairs per XCD group of that kernel (0 = all)
-    int opt_text_ln_fold = 0;    // text tower: LayerNorm folded into its GEMMs like the vision tower's (0: separate LayerNorm kernels)
+    int opt_text_ln_fold = 1;    // text tower: 1 (default) LayerNorm folded into its GEMMs with the LayerNorm weight in the ACTIVATION copy (GemmArgs::gamma:
+                                 // the GEMMs keep the layer's own fp16 weights - closer to the reference than the separate kernels, 4 % faster);
+                                 // 2 the weight folded into fp16(W * gamma) as in the vision tower (10 % faster, 7.6e-4 instead of 6.2e-4); 0 separate kernels
     int opt_qkv_attn_c = 1;      // ... also in the blocks that carry a folded adapter (variant C on the hi / lo stream: K = D + 64)
     int opt_mlp_fused = 0;       // blocks of width 512 (text tower): 1 = c_fc -> QuickGELU -> c_proj -> residual as ONE kernel for the rows that
                                  // fill whole rounds of 128-row items (hg_vae_fused.hip, mode 3), 2 = every row, 0 (default) = the two GEMMs:
@@ -329,13 +334,15 @@ int load_blocks(hg_ctx* c, std::vector<void*>& owned, const hg_block_weights* sr
         if (!fold_ln) continue;
         keep_first(rc, dev_alloc(c, owned, (size_t)3 * D * D * 2, (void**)&b.wf_qkv));
         keep_first(rc, dev_alloc(c, owned, (size_t)3 * D * 4, (void**)&b.cs_qkv));
+        keep_first(rc, dev_alloc(c, owned, (size_t)3 * D * 4, (void**)&b.csg_qkv));
+        keep_first(rc, dev_alloc(c, owned, (size_t)4 * D * 4, (void**)&b.csg_fc));
         keep_first(rc, dev_alloc(c, owned, (size_t)3 * D * 4, (void**)&b.bf_qkv));
         keep_first(rc, dev_alloc(c, owned, (size_t)4 * D * D * 2, (void**)&b.wf_fc));
         keep_first(rc, dev_alloc(c, owned, (size_t)4 * D * 4, (void**)&b.cs_fc));
         keep_first(rc, dev_alloc(c, owned, (size_t)4 * D * 4, (void**)&b.bf_fc));
         if (rc) return rc < 0 ? rc : HG_ERR_OOM;
-        HG_HIP(launch_fold_ln(b.w_qkv, b.ln1_w, b.ln1_b, b.b_qkv, b.wf_qkv, b.cs_qkv, b.bf_qkv, 3 * D, D, 0));
-        HG_HIP(launch_fold_ln(b.w_fc, b.ln2_w, b.ln2_b, b.b_fc, b.wf_fc, b.cs_fc, b.bf_fc, 4 * D, D, 0));
+        HG_HIP(launch_fold_ln(b.w_qkv, b.ln1_w, b.ln1_b, b.b_qkv, b.wf_qkv, b.cs_qkv, b.bf_qkv, 3 * D, D, 0, b.csg_qkv));
+        HG_HIP(launch_fold_ln(b.w_fc, b.ln2_w, b.ln2_b, b.b_fc, b.wf_fc, b.cs_fc, b.bf_fc, 4 * D, D, 0, b.csg_fc));
         if (qkv_attn_ok(1, 197, D, D / 64, D)) {      // (heads = width / 64 in every CLIP tower; L is checked per call)
             keep_first(rc, dev_alloc(c, owned, (size_t)3 * D * D * 2, (void**)&b.wp_qkv));
             keep_first(rc, dev_alloc(c, owned, (size_t)(D / 128) * 768 * 4, (void**)&b.bcs_qkv));
@@ -623,7 +630,7 @@ bool ln_fuse_ok(hg_ctx* c, int M, int D) {
 int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, int D, int heads, bool causal,
                hipStream_t s, float* trace, int trace_stride, const AdapterCall* ac, bool ln_fold,
                const float** row0_out = nullptr, const int32_t* sel = nullptr, const float* pre_w = nullptr,
-               const float* pre_b = nullptr, const float* pre_pos = nullptr, const float* pre_cls = nullptr) {
+               const float* pre_b = nullptr, const float* pre_pos = nullptr, const float* pre_cls = nullptr, bool gamma_act = false) {
     const int M = n_seq * L;
     const bool row0_env = c->opt_row0 != 0;
     if (row0_out) *row0_out = nullptr;
@@ -696,7 +703,13 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         if (pre_w) HG_HIP(launch_layernorm_rowstats(x, pre_w, pre_b, h_of(0), mr, mu, muc, M, D, s, pre_pos, pre_cls, L, ldh_of(0)));
         else {
             if (kmode.size() && kmode[0] == 2) kmode[0] = 0;      // rowstats_cast writes dense rows
-            HG_HIP(launch_rowstats_cast(x, h, mr, mu, M, D, s, muc));
+            if (gamma_act && !adapters) {
+                int rc2 = ensure(c, c->hg, gemm_lo_bytes(M, D));      // (fp16 pieces: 128 x 256 x 2 B per tile)
+                if (rc2) return rc2;
+                HG_HIP(launch_rowstats_cast(x, h, mr, mu, M, D, s, muc, blocks[0].ln1_w));
+            } else {
+                HG_HIP(launch_rowstats_cast(x, h, mr, mu, M, D, s, muc));
+            }
         }
     } else if (pre_w) {
         HG_HIP(launch_layernorm_f32(x, pre_w, pre_b, x, M, D, s, pre_pos, pre_cls, L));
@@ -743,6 +756,14 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         if (kmode[i] == 0) return true;
         return kmode[i] == 2 && hilo_c && c->opt_qkv_attn_c && c->vit.adapters[i].fold[ac->priors ? 0 : 1].wp_qcat != nullptr &&
                qkv_attn_ok(n_seq, L, D, heads, D + 64, D + 64);
+    };
+    // gs (text tower): the LayerNorm weight rides in the activation copy h (GemmArgs::gamma), the consumers multiply by the layer's own
+    // fp16 weights: no second rounding of W * gamma.  The stream's unscaled hi half then lives in c->hg, in fragment order
+    const bool gs = gamma_act && fuse && !adapters && pre_w == nullptr;
+    auto gs_args = [&](GemmArgs& g, const float* gamma) {
+        if (!gs) return;
+        g.gamma = gamma;
+        g.hif = (half_t*)c->hg.p;
     };
     int rln_i = 0;                  // index of the next LayerNorm-emitting residual GEMM
     bool x_is_hilo = false;         // the stream currently lives in (h, xlo, muc), not in x
@@ -793,6 +814,7 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
             HG_HIP(launch_qkv_attn(qa, s));
         } else if (fuse) {
             g.W = b.wf_qkv + qoff * D; g.bias = b.bf_qkv + qoff; g.cs = b.cs_qkv + qoff; g.mr = mr;
+            if (gs) { g.W = b.w_qkv + qoff * D; g.cs = b.csg_qkv + qoff; }
             HG_HIP(gemm(c, EPI_LN_BIAS_F16, g, s));
         } else {
             HG_HIP(launch_layernorm_f16(x, b.ln1_w, b.ln1_b, h, M, D, nullptr, 0, 1, s));
@@ -841,6 +863,7 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
             g.out2 = h; g.stats = stats; g.stats_ld = sld; g.mu = mu;
             if (hilo_c) { g.out2 = att; g.ld2 = D + 64; }      // the copy = the stream's hi half stays in [x16 | e]
             if (!kcat || hilo_c) rln_args(g);
+            gs_args(g, b.ln2_w);
             HG_HIP(gemm(c, EPI_RESID_LN_F32, g, s));
             HG_HIP(launch_finalize_stats(stats, mr, mu, M, sld, 64, s, muc));
         } else {
@@ -852,6 +875,7 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         if (fuse) {
             g.W = b.wf_fc; g.bias = b.bf_fc; g.cs = b.cs_fc; g.mr = mr;
             if (hilo_c) { g.A = att; g.lda = D + 64; }
+            if (gs) { g.W = b.w_fc; g.cs = b.csg_fc; }
             HG_HIP(gemm(c, EPI_LN_BIAS_QGELU_F16, g, s));
         } else {
             HG_HIP(launch_layernorm_f16(x, b.ln2_w, b.ln2_b, h, M, D, nullptr, 0, 1, s));
@@ -881,6 +905,7 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         if (fuse && i + 1 < blocks.size()) {      // the last block is followed by ln_post / ln_final on selected rows
             g.out2 = h_of(i + 1); g.ld2 = ldh_of(i + 1); g.stats = stats; g.stats_ld = sld; g.mu = mu;
             rln_args(g);
+            gs_args(g, blocks[i + 1].ln1_w);
             HG_HIP(gemm(c, EPI_RESID_LN_F32, g, s));
             HG_HIP(launch_finalize_stats(stats, mr, mu, M, sld, 64, s, muc));
         } else {
@@ -1042,7 +1067,7 @@ int hg_set_option(hg_ctx* c, const char* key, int value) {
         if (value < 0 || value > 6) return fail(c, HG_ERR_INVALID, "qkv_attn_gsz must be 0 .. 6 (got %d)", value);
         c->opt_qkv_attn_gsz = value;
     } else if (k == "text_ln_fold") {
-        if (value < 0 || value > 1) return fail(c, HG_ERR_INVALID, "text_ln_fold must be 0 or 1 (got %d)", value);
+        if (value < 0 || value > 2) return fail(c, HG_ERR_INVALID, "text_ln_fold must be 0, 1 or 2 (got %d)", value);
         c->opt_text_ln_fold = value;
     } else if (k == "qkv_attn_c") {
         if (value < 0 || value > 1) return fail(c, HG_ERR_INVALID, "qkv_attn_c must be 0 or 1 (got %d)", value);
@@ -1091,7 +1116,7 @@ void hg_destroy(hg_ctx* c) {
     for (auto& m : c->mlp) free_all(m.owned);
     for (auto& m : c->cache) free_all(m.owned);
     Buf* bufs[] = {&c->x, &c->h, &c->qkv, &c->att, &c->fc, &c->head16, &c->tok32, &c->small, &c->i32,
-                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq, &c->xlo, &c->zpark, &c->att2};
+                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq, &c->xlo, &c->zpark, &c->att2, &c->hg};
     for (Buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
@@ -1440,7 +1465,7 @@ int hg_profile_end(hg_ctx* c, hg_prof_rec* recs, int max_recs, int32_t* n_recs) 
 int hg_workspace_bytes(hg_ctx* c, uint64_t* bytes) {
     if (!c || !bytes) return HG_ERR_INVALID;
     Buf* bufs[] = {&c->x, &c->h, &c->qkv, &c->att, &c->fc, &c->head16, &c->tok32, &c->small, &c->i32,
-                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq, &c->xlo, &c->zpark, &c->att2};
+                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq, &c->xlo, &c->zpark, &c->att2, &c->hg};
     uint64_t t = 0;
     for (Buf* b : bufs) t += b->bytes;
     *bytes = t;
@@ -1851,7 +1876,8 @@ static int text_tail(hg_ctx* c, int Tc, int Leff, const int32_t* eot, float* out
     // the text tower keeps the separate LayerNorm by default: folding (option text_ln_fold) moves its parity error from 6.5e-4 to
     // 7.6e-4 (worst prompt 9.6e-4) of the 1e-3 budget; since the hi / lo stream it does buy time (600 x 77 tokens: 5.2 -> 4.6 ms)
     const float* rows = nullptr;      // dense EOT rows when the last block ran on them only
-    int rc = run_blocks(c, t.blocks, Tc, Leff, D, t.heads, true, s, nullptr, 0, nullptr, c->opt_text_ln_fold != 0, &rows, eot);
+    int rc = run_blocks(c, t.blocks, Tc, Leff, D, t.heads, true, s, nullptr, 0, nullptr, c->opt_text_ln_fold != 0, &rows, eot, nullptr,
+                        nullptr, nullptr, nullptr, c->opt_text_ln_fold == 1);
     if (rc) return rc;
     half_t* h16 = (half_t*)c->head16.p;
     // ln_final, select the EOT row, @ text_projection (clipnet/model.py:346-350); LN is row-wise so

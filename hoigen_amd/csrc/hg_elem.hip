@@ -533,34 +533,38 @@ hipError_t launch_copy_cols(const float* x, int ld, float* out, int R, int N, hi
 __global__ __launch_bounds__(256) void fold_ln_kernel(const half_t* __restrict__ w16, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, const float* __restrict__ bias,
                                                       half_t* __restrict__ wf16, float* __restrict__ cs,
-                                                      float* __restrict__ bf, int N, int K) {
+                                                      float* __restrict__ bf, int N, int K, float* __restrict__ csg) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
-    float c = 0.f, b = 0.f;
+    float c = 0.f, b = 0.f, cg = 0.f;
     for (int k = lane; k < K; k += 64) {
         const float w = (float)w16[(size_t)n * K + k];
         const half_t wf = (half_t)(w * gamma[k]);
         wf16[(size_t)n * K + k] = wf;
         c += (float)wf;
         b += w * beta[k];
+        cg += w * gamma[k];
     }
     c = wave_sum(c);
     b = wave_sum(b);
+    cg = wave_sum(cg);
     if (lane == 0) {
         cs[n] = c;
         bf[n] = (bias ? bias[n] : 0.f) + b;
+        // column sums for the form that keeps gamma in the ACTIVATION copy and W unrounded (GemmArgs::gamma): sum_k gamma[k] W[n][k]
+        if (csg) csg[n] = cg;
     }
 }
 hipError_t launch_fold_ln(const half_t* w16, const float* gamma, const float* beta, const float* bias, half_t* wf16,
-                          float* cs, float* bf, int N, int K, hipStream_t s) {
-    hipLaunchKernelGGL(fold_ln_kernel, dim3((N + 3) / 4), dim3(256), 0, s, w16, gamma, beta, bias, wf16, cs, bf, N, K);
+                          float* cs, float* bf, int N, int K, hipStream_t s, float* csg) {
+    hipLaunchKernelGGL(fold_ln_kernel, dim3((N + 3) / 4), dim3(256), 0, s, w16, gamma, beta, bias, wf16, cs, bf, N, K, csg);
     return hipGetLastError();
 }
 
 __global__ __launch_bounds__(256) void rowstats_cast_kernel(const float* __restrict__ x, half_t* __restrict__ x16,
                                                             float* __restrict__ mr, float* __restrict__ mu, int M, int D,
-                                                            float* __restrict__ muc) {
+                                                            float* __restrict__ muc, const float* __restrict__ gamma) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= M) return;
@@ -583,11 +587,12 @@ __global__ __launch_bounds__(256) void rowstats_cast_kernel(const float* __restr
         const int c = lane + 64 * i;
         if (c < nc) {
             half4 h;
+            const f32x4 gm = gamma ? reinterpret_cast<const f32x4*>(gamma)[c] : f32x4{1.f, 1.f, 1.f, 1.f};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float d = v[i][e] - mean;
                 q += d * d;
-                h[e] = (half_t)d;
+                h[e] = gamma ? (half_t)(d * gm[e]) : (half_t)d;      // (gamma: the copy carries the next LayerNorm's weight, GemmArgs::gamma)
             }
             reinterpret_cast<half4*>(x16 + (size_t)r * D)[c] = h;
         }
@@ -689,10 +694,11 @@ hipError_t launch_layernorm_rowstats(float* x, const float* w, const float* b, h
                        ld16);
     return hipGetLastError();
 }
-hipError_t launch_rowstats_cast(const float* x, half_t* x16, float* mr, float* mu, int M, int D, hipStream_t s, float* muc) {
+hipError_t launch_rowstats_cast(const float* x, half_t* x16, float* mr, float* mu, int M, int D, hipStream_t s, float* muc,
+                                const float* gamma) {
     if (M <= 0) return hipSuccess;
     if (D % 4 || D > 256 * LN_MAXC) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(rowstats_cast_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, x16, mr, mu, M, D, muc);
+    hipLaunchKernelGGL(rowstats_cast_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, x16, mr, mu, M, D, muc, gamma);
     return hipGetLastError();
 }
 

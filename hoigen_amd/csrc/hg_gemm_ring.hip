@@ -962,7 +962,7 @@ hipError_t launch_gemm_ring(int epi, const GemmArgs& a, hipStream_t s) {
     if (resid && epi != EPI_RESID_LN_F32 && t256 >= 256 && (double)rounds <= 0.8 * rounds128 + 1e-9) big = true;
     if (force_big == 1) big = true;
     if (force_big == 2 || force_big == 3) big = false;
-    if (epi == EPI_RESID_LN_F32 && (!big || a.hl)) return launch_gemm_ring2(epi, a, s);     // no 128-row variant in this kernel; the hi / lo stream lives in ring2's tile order
+    if (epi == EPI_RESID_LN_F32 && (!big || a.hl || a.gamma)) return launch_gemm_ring2(epi, a, s);     // no 128-row variant in this kernel; the hi / lo stream lives in ring2's tile order
     if (!big && force_big != 3 && !lnc && gemm_ring2_ok(a)) return launch_gemm_ring2(epi, a, s);   // 128x256, two-phase
     // 256x256 tiles run two phases per K-tile (32 MFMAs per segment): -4..8 % vs four phases (HG_RING_PH2=0 in experiments builds)
     // ... except with the residual epilogues: their rolling window does not fit beside the two-phase loop's fragment

@@ -45,7 +45,12 @@ namespace hg {
 // side, 64 lanes contiguous - whole lines in, whole lines out.  lo is bf8 (HG_LO8, hg_kernels.h: 2 x 4 B per lane; 6 bytes per
 // element through the epilogue) or fp16 (2 x 8 B; 8 bytes) instead of the fp32 stream's 10, and 16 instead of 24 partial-line
 // store instructions per wave and tile.
-template <int EPI, int HL = 0>
+// GS (EPI_RESID_LN_F32 only; GemmArgs::gamma): the copy the next GEMM reads is fp16((x' - mu) * gamma[n]) - the next LayerNorm's weight
+// rides in the ACTIVATION copy, so that the consuming GEMM multiplies by the layer's own fp16 weights (as the reference does) and not by
+// a re-rounded fp16(W * gamma): the folded text tower's excess error against the reference was that second rounding
+// (tests/test_gpu_text_fold_study.py).  out2 is always that scaled copy; where the stream is held as hi + lo its unscaled
+// hi then lives in `hif`, in the tile-fragment order of lo (whole 16-byte pieces per lane; only this kernel's epilogue reads it).
+template <int EPI, int HL = 0, bool GS = false>
 __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int tiles_n, const int n_tiles,
                                                      const unsigned a_bytes, const int mode, const int gsz) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins (buffer resources, LDS DMA): host sees just the stub
@@ -69,7 +74,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
     constexpr bool F16OUT = (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_QGELU_F16 || EPI == EPI_BIAS_RELU_F16);
     static_assert(HL == 0 || EPI == EPI_RESID_LN_F32, "hi / lo stream: EPI_RESID_LN_F32 only");
     constexpr bool IN_HL = (HL == 2 || HL == 3), OUT_HL = (HL == 1 || HL == 2);
-    constexpr int E = F16OUT ? 8 : (RLN ? (OUT_HL ? 20 : 28) : 16);    // epilogue store instructions per wave
+    static_assert(!GS || EPI == EPI_RESID_LN_F32, "gamma-scaled copy: EPI_RESID_LN_F32 only");
+    constexpr int E = F16OUT ? 8 : (RLN ? (OUT_HL ? (GS ? 28 : 20) : 28) : 16);    // epilogue store instructions per wave
     constexpr int R = RESID ? (RLN ? (IN_HL ? 24 : 20) : 16) : 0;      // residual (+ row centre) prefetch loads per wave
     constexpr int BIAS_OFF = NST * STAGE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -275,6 +281,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
         const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int i = tid; i < p.N / 4; i += 512)
             *reinterpret_cast<f32x4*>(smem + BIAS_OFF + i * 16) = p.bias ? reinterpret_cast<const f32x4*>(p.bias)[i] : z;
+        if constexpr (GS)      // the next LayerNorm's weight behind the bias
+            for (int i = tid; i < p.N / 4; i += 512)
+                *reinterpret_cast<f32x4*>(smem + BIAS_OFF + p.N * 4 + i * 16) = reinterpret_cast<const f32x4*>(p.gamma)[i];
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
     // ---- prologue: W(0) A(0) W(1) A(1) W(2); A(2) is issued by the first PA, W(3) by the first PB
@@ -319,6 +328,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
             return p.lo + ((((size_t)tm_ * tiles_n + tn_) * 8 + wave) * 8 + (ha * 4 + hb * 2 + g2)) * (HG_LO8 ? 256 : 512) +
                    lane * (HG_LO8 ? 4 : 8);
         };
+        auto hif_ptr = [&](int tm_, int tn_, int ha, int hb, int g2) {      // (GS) hi piece: 64 lanes x 16 B
+            return p.hif + ((((size_t)tm_ * tiles_n + tn_) * 8 + wave) * 8 + (ha * 4 + hb * 2 + g2)) * 512 + lane * 8;
+        };
         // One K-tile.  KIND: 0 middle, 1 first of a tile (the previous epilogue's stores may be pending), 2 / 3 / 4 the
         // third-to-last, second-to-last and last K-tile of a tile: only there the refills (A at distance 2, W at
         // distance 3) and the waits depend on whether another tile follows.  K >= 256 keeps the kinds distinct.
@@ -343,8 +355,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                         for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
                             for (int g2 = 0; g2 < 2; ++g2) {
-                                xhi[ha][hb][g2] = *reinterpret_cast<const u32x4_hl*>(
-                                    p.out2 + (size_t)mp * p.ld2 + n0 + hb * 128 + wn * 32 + g2 * 16 + 4 * (qq & ~1));
+                                if constexpr (GS)      // the unscaled hi half in fragment order: this lane's two row tiles side by side
+                                    xhi[ha][hb][g2] = *reinterpret_cast<const u32x4_hl*>(hif_ptr(tm, tn, ha, hb, g2));
+                                else
+                                    xhi[ha][hb][g2] = *reinterpret_cast<const u32x4_hl*>(
+                                        p.out2 + (size_t)mp * p.ld2 + n0 + hb * 128 + wn * 32 + g2 * 16 + 4 * (qq & ~1));
                                 if constexpr (HG_LO8) {
                                     typedef unsigned u32x2_hl __attribute__((ext_vector_type(2)));
                                     const u32x2_hl l8 = *reinterpret_cast<const u32x2_hl*>(lo_ptr(tm, tn, ha, hb, g2));
@@ -470,6 +485,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
 #pragma unroll
             for (int ha = 0; ha < 2; ++ha) {
                 half4 h16[2][2][2];                         // [f][hb][g2]: the new copy (hi)
+                half4 g16[GS && OUT_HL ? 2 : 1][GS && OUT_HL ? 2 : 1][GS && OUT_HL ? 2 : 1];      // ... times gamma, where hi must stay unscaled
                 half4 l16[OUT_HL ? 2 : 1][OUT_HL ? 2 : 1][OUT_HL ? 2 : 1];
                 unsigned l8[OUT_HL ? 2 : 1][OUT_HL ? 2 : 1][OUT_HL ? 2 : 1];      // HG_LO8: the remainder as four bf8 (e5m2)
                 half4 hin[IN_HL ? 2 : 1][IN_HL ? 2 : 1][IN_HL ? 2 : 1];
@@ -482,10 +498,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
 #pragma unroll
                         for (int g2 = 0; g2 < 2; ++g2) {
                             const u32x4_hl o = xhi[ha][hb][g2], l = xlo[ha][hb][g2];
-                            const auto s0 = __builtin_amdgcn_permlane16_swap(o[0], o[2], false, false);
-                            const auto s1 = __builtin_amdgcn_permlane16_swap(o[1], o[3], false, false);
-                            hin[0][hb][g2] = __builtin_bit_cast(half4, u32x2{(unsigned)s0[0], (unsigned)s1[0]});
-                            hin[1][hb][g2] = __builtin_bit_cast(half4, u32x2{(unsigned)s0[1], (unsigned)s1[1]});
+                            if constexpr (GS) {      // (fragment order: no exchange)
+                                hin[0][hb][g2] = __builtin_bit_cast(half4, u32x2{o[0], o[1]});
+                                hin[1][hb][g2] = __builtin_bit_cast(half4, u32x2{o[2], o[3]});
+                            } else {
+                                const auto s0 = __builtin_amdgcn_permlane16_swap(o[0], o[2], false, false);
+                                const auto s1 = __builtin_amdgcn_permlane16_swap(o[1], o[3], false, false);
+                                hin[0][hb][g2] = __builtin_bit_cast(half4, u32x2{(unsigned)s0[0], (unsigned)s1[0]});
+                                hin[1][hb][g2] = __builtin_bit_cast(half4, u32x2{(unsigned)s0[1], (unsigned)s1[1]});
+                            }
                             if constexpr (HG_LO8) {
 #pragma unroll
                                 for (int f = 0; f < 2; ++f) {
@@ -543,7 +564,17 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
 #pragma unroll
                             for (int e2 = 0; e2 < 2; ++e2) {
                                 const f32x2 d = f32x2{v[hb][g2][2 * e2], v[hb][g2][2 * e2 + 1]} - mu2;
-                                const half2v hh = __builtin_convertvector(d, half2v);
+                                half2v hh = __builtin_convertvector(d, half2v);
+                                if constexpr (GS) {
+                                    const f32x2 gm2 = *reinterpret_cast<const f32x2*>(smem + BIAS_OFF + p.N * 4 + (n + 2 * e2) * 4);
+                                    const half2v hg = __builtin_convertvector(d * gm2, half2v);
+                                    if constexpr (OUT_HL) {
+                                        g16[f][hb][g2][2 * e2] = hg[0];
+                                        g16[f][hb][g2][2 * e2 + 1] = hg[1];
+                                    } else {
+                                        hh = hg;      // (the stream leaves as fp32: the copy has no second role)
+                                    }
+                                }
                                 h16[f][hb][g2][2 * e2] = hh[0];
                                 h16[f][hb][g2][2 * e2 + 1] = hh[1];
                                 if constexpr (OUT_HL) {
@@ -591,11 +622,17 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
 #pragma unroll
                     for (int g2 = 0; g2 < 2; ++g2) {
                         const int nb = n0 + hb * 128 + wn * 32 + g2 * 16;
-                        const u32x2 ux = __builtin_bit_cast(u32x2, h16[0][hb][g2]), uy = __builtin_bit_cast(u32x2, h16[1][hb][g2]);
+                        // (GS with the stream as hi + lo: the row-major copy is the scaled one, the unscaled hi goes out in fragment order)
+                        const u32x2 ux = __builtin_bit_cast(u32x2, (GS && OUT_HL) ? g16[0][hb][g2] : h16[0][hb][g2]);
+                        const u32x2 uy = __builtin_bit_cast(u32x2, (GS && OUT_HL) ? g16[1][hb][g2] : h16[1][hb][g2]);
                         const auto s0 = __builtin_amdgcn_permlane16_swap(ux[0], uy[0], false, false);
                         const auto s1 = __builtin_amdgcn_permlane16_swap(ux[1], uy[1], false, false);
                         const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
                         if (INTERIOR || m < p.M) *reinterpret_cast<u32x4*>(out2 + (size_t)m * p.ld2 + nb + 4 * (q & ~1)) = o;
+                        if constexpr (GS && OUT_HL) {
+                            const u32x2 hx = __builtin_bit_cast(u32x2, h16[0][hb][g2]), hy = __builtin_bit_cast(u32x2, h16[1][hb][g2]);
+                            *reinterpret_cast<u32x4*>(hif_ptr(tm, tn, ha, hb, g2)) = u32x4{hx[0], hx[1], hy[0], hy[1]};
+                        }
                         if constexpr (OUT_HL) {      // the remainder: this lane's two row tiles side by side, the wave's piece contiguous
                             if constexpr (HG_LO8) {
                                 *reinterpret_cast<u32x2*>(lo_ptr(tm, tn, ha, hb, g2)) = u32x2{l8[0][hb][g2], l8[1][hb][g2]};
@@ -648,10 +685,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
 #endif
 }
 
-template <int EPI, int HL = 0>
+template <int EPI, int HL = 0, bool GS = false>
 static hipError_t launch_ring2_t(const GemmArgs& a, hipStream_t s) {
     constexpr int RING = 3 * 49152;
-    const int LDS = RING + a.N * 4;
+    const int LDS = RING + a.N * 4 * (GS ? 2 : 1);
     if (LDS > 160 * 1024) return hipErrorInvalidValue;
     static bool attr_set_d[HG_MAX_DEVICES] = {};      // function attributes and CU counts are per device
     static int n_cu_d[HG_MAX_DEVICES];
@@ -660,7 +697,7 @@ static hipError_t launch_ring2_t(const GemmArgs& a, hipStream_t s) {
     int& n_cu = n_cu_d[dev_i];
     if (!attr_set) {
         n_cu = 256;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring2<EPI, HL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring2<EPI, HL, GS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         int dev = 0;
@@ -704,7 +741,7 @@ static hipError_t launch_ring2_t(const GemmArgs& a, hipStream_t s) {
         hipMemsetAsync(d, 0, n * 8, s);
         GemmArgs b = a;
         b.dbg = d;
-        hipLaunchKernelGGL((gemm_ring2<EPI, HL>), dim3(grid), dim3(512), LDS, s, b, tiles_n, n_tiles, (unsigned)a_bytes, mode, gsz);
+        hipLaunchKernelGGL((gemm_ring2<EPI, HL, GS>), dim3(grid), dim3(512), LDS, s, b, tiles_n, n_tiles, (unsigned)a_bytes, mode, gsz);
         hipStreamSynchronize(s);
         unsigned long long* h = (unsigned long long*)malloc(n * 8);
         hipMemcpy(h, d, n * 8, hipMemcpyDeviceToHost);
@@ -724,7 +761,7 @@ static hipError_t launch_ring2_t(const GemmArgs& a, hipStream_t s) {
         return hipGetLastError();
     }
 #endif
-    hipLaunchKernelGGL((gemm_ring2<EPI, HL>), dim3(grid), dim3(512), LDS, s, a, tiles_n, n_tiles, (unsigned)a_bytes, mode, gsz);
+    hipLaunchKernelGGL((gemm_ring2<EPI, HL, GS>), dim3(grid), dim3(512), LDS, s, a, tiles_n, n_tiles, (unsigned)a_bytes, mode, gsz);
     return hipGetLastError();
 }
 
@@ -746,6 +783,16 @@ hipError_t launch_gemm_ring2(int epi, const GemmArgs& a_in, hipStream_t s) {
         case EPI_SCALE_RESID_F32: return launch_ring2_t<EPI_SCALE_RESID_F32>(a, s);
         case EPI_RESID_LN_F32:
             if (a.hl && (!a.lo || !a.mu || ((a.hl == 2 || a.hl == 3) && !a.muc))) return hipErrorInvalidValue;      // (the hi half lives at out2 with row stride ld2: any)
+            if (a.gamma) {      // the copy scaled by the next LayerNorm's weight (hl != 0: the stream's hi half lives in hif)
+                if (a.hl && !a.hif) return hipErrorInvalidValue;
+                switch (a.hl) {
+                    case 0: return launch_ring2_t<EPI_RESID_LN_F32, 0, true>(a, s);
+                    case 1: return launch_ring2_t<EPI_RESID_LN_F32, 1, true>(a, s);
+                    case 2: return launch_ring2_t<EPI_RESID_LN_F32, 2, true>(a, s);
+                    case 3: return launch_ring2_t<EPI_RESID_LN_F32, 3, true>(a, s);
+                    default: return hipErrorInvalidValue;
+                }
+            }
             switch (a.hl) {
                 case 0: return launch_ring2_t<EPI_RESID_LN_F32, 0>(a, s);
                 case 1: return launch_ring2_t<EPI_RESID_LN_F32, 1>(a, s);

@@ -76,6 +76,12 @@ struct GemmArgs {
     int hl = 0;
     half_t* lo = nullptr;
     const float* muc = nullptr;
+    // EPI_RESID_LN_F32 (gemm_ring2): gamma [N] = the NEXT LayerNorm's weight, multiplied into the copy the next GEMM reads -
+    // out2 = fp16((x - mu) * gamma) - so that GEMM runs on the layer's own fp16 weights with cs[n] = sum_k gamma[k] W[n][k] (fold_ln's csg).
+    // Where the stream is held as hi + lo (hl != 0) its unscaled hi half then lives in `hif` (gemm_lo_bytes(M, N) * 2 bytes, tile-fragment
+    // order like lo: written by hl 1 / 2, read by hl 2 / 3) instead of being that copy.
+    const float* gamma = nullptr;
+    half_t* hif = nullptr;
 };
 // bytes of the `lo` buffer for M rows x N columns (whole 128 x 256 tiles)
 inline size_t gemm_lo_bytes(int M, int N) { return (size_t)((M + 127) / 128) * (N / 256) * 65536; }
@@ -216,10 +222,10 @@ hipError_t launch_copy_cols(const float* x, int ld, float* out, int R, int N, hi
 // ---- LayerNorm folding support (DESIGN.md §4 "LayerNorm folded into the GEMMs")
 // W16 [N,K], gamma/beta [K], bias [N]  ->  Wf16 = fp16(W * gamma), cs[n] = sum_k float(Wf16[n][k]), bf[n] = bias[n] + sum_k W[n][k] * beta[k]
 hipError_t launch_fold_ln(const half_t* w16, const float* gamma, const float* beta, const float* bias, half_t* wf16,
-                          float* cs, float* bf, int N, int K, hipStream_t s);
+                          float* cs, float* bf, int N, int K, hipStream_t s, float* csg = nullptr);
 // x fp32 [M,D] -> centred fp16 copy x16 = fp16(x - mean), mu[m] = mean, mr[m] = (0, rstd) (eps 1e-5, biased variance)
 hipError_t launch_rowstats_cast(const float* x, half_t* x16, float* mr, float* mu, int M, int D, hipStream_t s,
-                                float* muc = nullptr);   // muc (optional): centre of the copy as well (= mu)
+                                float* muc = nullptr, const float* gamma = nullptr);   // muc (optional): centre of the copy as well (= mu)
 // x = LayerNorm(x; w, b) in place (fp32) followed by rowstats_cast of the result, in one pass (ln_pre of the vision tower)
 hipError_t launch_layernorm_rowstats(float* x, const float* w, const float* b, half_t* x16, float* mr, float* mu, float* muc,
                                      int M, int D, hipStream_t s, const float* pos = nullptr, const float* cls = nullptr,

@@ -36,14 +36,14 @@ class Branch:
 
 
 class FeatureSampler:
-    def __init__(self, clip_model: CLIP, branches: "Dict[str, Branch]", fold_text_layernorm: bool = False):
-        """``fold_text_layernorm``: run the text tower with its LayerNorms folded into the GEMMs while sampling (library option
-        ``text_ln_fold``, include/hoigen_amd.h: 11 % faster - 2.95 -> 2.62 ms per iteration of the HICO loop - for 1e-4 of the 1e-3
-        parity tolerance against the reference; off by default like the option itself)."""
+    def __init__(self, clip_model: CLIP, branches: "Dict[str, Branch]", text_ln_fold: Optional[int] = None):
+        """``text_ln_fold``: value of the library option of that name (include/hoigen_amd.h) for the duration of ``sample()``; None keeps
+        the model's setting (default 1: LayerNorm folded with its weight in the activation copy).  2 = the weight folded into the GEMM
+        weights: the HICO loop 2.8 -> 2.6 ms per iteration for 1.4e-4 of the 1e-3 parity tolerance against the reference."""
         self.clip = clip_model
         self.branches = branches
         self.text_encoder = vae.TextEncoder(clip_model)
-        self.fold_text_layernorm = bool(fold_text_layernorm)
+        self.text_ln_fold = text_ln_fold
 
     def _tokens_run(self) -> int:
         """max(EOT) + 1 over every class of every branch: the tokens the truncated text tower reads (clipnet/model.py:350 selects the
@@ -113,8 +113,8 @@ class FeatureSampler:
         feats: "Dict[str, List[torch.Tensor]]" = {k: [] for k in self.branches}
         saved = {k: b.target for k, b in self.branches.items()}
         done = 0
-        if self.fold_text_layernorm:
-            self.clip.set_option("text_ln_fold", 1)
+        if self.text_ln_fold is not None:
+            self.clip.set_option("text_ln_fold", int(self.text_ln_fold))
         try:
             while done < iterations:
                 k_it = min(max(1, batch_iters), iterations - done)
@@ -129,8 +129,8 @@ class FeatureSampler:
         finally:
             for k, b in self.branches.items():
                 b.target = saved[k]
-            if self.fold_text_layernorm:
-                self.clip.set_option("text_ln_fold", 0)
+            if self.text_ln_fold is not None:
+                self.clip.set_option("text_ln_fold", 1)      # (the library default)
         gen_feature = torch.cat([torch.cat(feats[k], dim=0) for k in self.branches], dim=0)
         gen_target = torch.cat([b.target.to(dev).repeat(iterations) for b in self.branches.values()], dim=0)
         return gen_feature, gen_target

@@ -248,11 +248,14 @@ int hg_vae_loss(hg_ctx*, const float* recon, const float* x, const float* mean, 
  *                      of its (sequence, head pair) items is well filled: speed only).  Bit-identical results either way.
  *   "qkv_attn_min_seq" [HG_QKV_ATTN_MIN_SEQ] ... from this many sequences per call on (default 32)
  *   "qkv_attn_gsz"    [HG_QKV_ATTN_GSZ]    head pairs per XCD group of that kernel (0 = all six side by side; speed only)
- *   "text_ln_fold"    [HG_TEXT_LN_FOLD]    1: the text tower's LayerNorms are folded into its GEMMs as the vision tower's are (600 prompts x 77
- *                      tokens: 5.2 -> 4.6 ms); 0 (default): separate LayerNorm kernels, which round where the reference rounds - against its
- *                      outputs 6.5e-4 (worst prompt 7.9e-4) instead of 7.6e-4 (worst prompt 9.6e-4) of the 1e-3 tolerance.  Calls of fewer
- *                      than 512 rows (prompts x executed tokens) keep the separate kernels either way, so with the option on a prompt's
- *                      bits depend on whether its call was that small (with it off they never depend on the batch).
+ *   "text_ln_fold"    [HG_TEXT_LN_FOLD]    how the text tower's LayerNorms reach its GEMMs.  1 (default): folded, with the LayerNorm weight
+ *                      multiplied into the fp16 ACTIVATION copy the residual GEMM hands on, so that in_proj / c_fc run on the layer's own
+ *                      fp16 weights as the reference does (600 prompts x 77 tokens: 5.35 -> 5.15 ms; against the reference's outputs 6.2e-4,
+ *                      worst prompt 7.5e-4); 0: separate LayerNorm kernels (6.5e-4, worst prompt 7.9e-4); 2: the weight folded into
+ *                      fp16(W * gamma) as in the vision tower - the fastest (4.8 ms) and, through that second rounding of the weights, the
+ *                      least close (7.6e-4, worst prompt 9.6e-4 of the 1e-3 tolerance).  Calls of fewer than 512 rows (prompts x executed
+ *                      tokens) take the separate kernels whatever the setting (as the vision tower does below 512 rows): a prompt's bits
+ *                      depend on which of the two paths its call takes, never on its neighbours in the call.
  *   "qkv_attn_c"      [HG_QKV_ATTN_C]      1 (default): also in the blocks whose instance adapter is folded into in_proj (variant C on the
  *                      hi / lo stream: the same kernel summing over D + 64 columns); 0: those blocks keep the two kernels.  Bit-identical.
  *   "vae_fused"       [HG_VAE_FUSED]       1: hg_vae_forward / hg_generator run Encoder -> reparameterise -> Generator as ONE kernel

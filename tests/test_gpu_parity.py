@@ -408,8 +408,9 @@ def test_batch256_invariance_and_determinism(fullA):
 
 def test_layernorm_folding_matches_separate_layernorm(fullA, g0, monkeypatch):
     """The vision tower folds LayerNorm into its GEMMs for M >= 512; option ln_fuse = 0 selects the separate-LayerNorm
-    path.  Both must sit within the parity tolerance of the reference and of each other; the text tower always
-    uses the separate LayerNorm (its error budget is tighter)."""
+    path.  Both must sit within the parity tolerance of the reference and of each other.  The switch reaches the text tower as well
+    (it folds by default since round 5: option text_ln_fold): with ln_fuse = 0 it runs the separate kernels, the same bits as
+    text_ln_fold = 0."""
     g = dict(np.load(f"{G}/g2_vitb16_image.npz"))
     img = torch.from_numpy(synth.crops(4, 224, seed=1234)).to(dev())
     ids = clip.tokenize(g0["obj81"]["text"]).to(dev())
@@ -424,7 +425,15 @@ def test_layernorm_folding_matches_separate_layernorm(fullA, g0, monkeypatch):
         fullA.set_option("ln_fuse", 1)
     assert not torch.equal(outs[1][0], outs[0][0]), "the switch did not change the executed path"
     check(outs[1][0], outs[0][0].cpu().numpy(), what="folded vs separate LayerNorm (image)")
-    assert torch.equal(outs[1][1], outs[0][1]), "the text tower does not fold LayerNorm"
+    g3 = dict(np.load(f"{G}/g3_vitb16_text.npz"))
+    for mode in (1, 0):
+        check(outs[mode][1], g3["obj81"], what=f"encode_text ln_fuse={mode}")
+    assert not torch.equal(outs[1][1], outs[0][1]), "ln_fuse = 0 did not reach the text tower"
+    try:
+        fullA.set_option("text_ln_fold", 0)
+        assert torch.equal(fullA.encode_text(ids).float(), outs[0][1]), "ln_fuse = 0 and text_ln_fold = 0 are the same path"
+    finally:
+        fullA.set_option("text_ln_fold", 1)
 
 
 def _stream_lo_bits(model) -> int:
@@ -466,10 +475,26 @@ def test_last_block_on_class_rows_only_matches_full_last_block(fullA, g0, monkey
     check(outs[1][1][-2], outs[0][1][-2].cpu().numpy(), tol=2e-6 if _stream_lo_bits(fullA) == 16 else 1e-4,
           what="class rows after the second-to-last block")
     check(outs[1][1][-1], outs[0][1][-1].cpu().numpy(), what="class rows after the last block")
-    # the text tower (EOT rows) keeps the separate LayerNorm in both modes, and the 128x128 GEMM kernel of the dense
-    # rows accumulates in the same order as the ring kernels: bit-identical
+    # the text tower (EOT rows): with its LayerNorms folded (the default) the two arrangements differ like the image tower's do - the last
+    # block's rows take the separate kernels on the dense EOT rows, the folded GEMMs on all rows - and agree within the tolerance; with the
+    # separate kernels throughout (text_ln_fold = 0) the 128x128 GEMM kernel of the dense rows accumulates in the same order as the ring
+    # kernels: bit-identical
     for trunc in (True, False):
-        assert torch.equal(txt[1, trunc], txt[0, trunc]), f"text tower, EOT rows only (truncate={trunc})"
+        check(txt[1, trunc], txt[0, trunc].cpu().numpy(), what=f"text tower, EOT rows only vs every row (truncate={trunc})")
+    try:
+        fullA.set_option("text_ln_fold", 0)
+        sep = {}
+        for mode in (1, 0):
+            fullA.set_option("last_block_row0", mode)
+            for trunc in (True, False):
+                fullA.truncate_text = trunc
+                sep[mode, trunc] = fullA.encode_text(ids).float()
+        for trunc in (True, False):
+            assert torch.equal(sep[1, trunc], sep[0, trunc]), f"text tower, separate LayerNorm, EOT rows only (truncate={trunc})"
+    finally:
+        fullA.set_option("text_ln_fold", 1)
+        fullA.set_option("last_block_row0", 1)
+        fullA.truncate_text = True
 
 
 def test_text_truncation_is_exact_selection(fullA, g0):
@@ -681,6 +706,7 @@ def test_text_mlp_block_as_one_kernel_vs_reference(fullA, g0):
     outs = {}
     try:
         fullA.truncate_text = False
+        fullA.set_option("text_ln_fold", 0)      # (the one-kernel MLP belongs to the separate-LayerNorm path)
         for mode in (0, 1, 2):
             fullA.set_option("mlp_fused", mode)
             outs[mode] = fullA.encode_text(ids).float()
@@ -688,6 +714,7 @@ def test_text_mlp_block_as_one_kernel_vs_reference(fullA, g0):
             print(f"\nencode_text (600 prompts x 77) rel-L2 vs reference, mlp_fused={mode}: {e:.3e}")
     finally:
         fullA.set_option("mlp_fused", 0)
+        fullA.set_option("text_ln_fold", 1)
         fullA.truncate_text = True
     assert not torch.equal(outs[0], outs[2]) and not torch.equal(outs[0], outs[1])
     check(outs[2], outs[0].cpu().numpy(), tol=9e-4, what="one-kernel MLP vs two GEMMs")      # (two realisations of the fp16 roundings of 12 blocks, each 6.5e-4 from the reference)
@@ -783,48 +810,51 @@ def test_variant_c_non_finite_crop_does_not_poison_its_neighbours():
 
 
 def test_text_tower_with_folded_layernorm_vs_reference(fullA, g0):
-    """Option text_ln_fold = 1 (off by default): the text tower's LayerNorms folded into its GEMMs like the vision tower's (statistics from
-    the residual GEMMs' epilogues, the stream as centre + hi + lo).  11 % faster at 77 tokens, and one more rounding arrangement away from
-    the reference's (which rounds the LayerNorm OUTPUT to fp16 as the separate kernels do): whole-tensor 7.6e-4 instead of 6.5e-4, worst
-    prompt 9.6e-4 - inside the 1e-3 tolerance on every prompt of the three sets, which is why it is an option and not the default.  Also:
-    the option really switches the path, truncation keeps its bits, and the default path is back afterwards."""
+    """Option text_ln_fold: how the text tower's LayerNorms reach its GEMMs.  1 (default since round 5): folded, the LayerNorm weight
+    multiplied into the ACTIVATION copy the residual GEMM hands on (GemmArgs::gamma), so that in_proj / c_fc run on the layer's own fp16
+    weights as the reference does - 6.2e-4 against its outputs (worst prompt of the 600 + 81 + 117 sets 7.5e-4); 0: the separate
+    kernels (6.5e-4, worst 7.9e-4); 2: the weight folded into fp16(W * gamma) like the vision tower's - the fastest and, through that
+    second rounding of the weights, the least close (7.6e-4, worst 9.6e-4: tests/test_gpu_text_fold_study.py).  All three against the
+    reference on every prompt; the settings really differ; truncation keeps each setting's bits; the default comes back."""
     g3 = dict(np.load(f"{G}/g3_vitb16_text.npz"))
     ids = {n: clip.tokenize(g0[n]["text"]).to(dev()) for n in ("hoi600", "obj81", "verb117")}
-    fullA.truncate_text = False
-    base = fullA.encode_text(ids["hoi600"]).float()
+    outs, errs = {}, {}
     try:
-        fullA.set_option("text_ln_fold", 1)
-        for name in ("hoi600", "obj81", "verb117"):
-            fullA.truncate_text = False
-            full = fullA.encode_text(ids[name]).float()
-            e = check(full, g3[name], what=f"encode_text {name}, folded LayerNorm")
-            fullA.truncate_text = True
-            assert torch.equal(fullA.encode_text(ids[name]).float(), full), "truncation changed the folded path's rows"
-            print(f"\nencode_text {name}, folded LayerNorm: rel-L2 vs reference {e:.3e}")
-            if name == "hoi600":
-                assert not torch.equal(full, base), "the option did not change the executed path"
+        for mode in (1, 0, 2):
+            fullA.set_option("text_ln_fold", mode)
+            for name in ("hoi600", "obj81", "verb117"):
+                fullA.truncate_text = False
+                full = fullA.encode_text(ids[name]).float()
+                errs[mode, name] = check(full, g3[name], what=f"encode_text {name}, text_ln_fold={mode}")
+                fullA.truncate_text = True
+                assert torch.equal(fullA.encode_text(ids[name]).float(), full), f"truncation changed the rows (text_ln_fold={mode})"
+                if name == "hoi600":
+                    outs[mode] = full
+            print(f"\nencode_text rel-L2 vs reference, text_ln_fold={mode}: " + ", ".join(f"{n} {errs[mode, n]:.3e}" for n in ids))
     finally:
-        fullA.set_option("text_ln_fold", 0)
+        fullA.set_option("text_ln_fold", 1)
         fullA.truncate_text = False
-    assert torch.equal(fullA.encode_text(ids["hoi600"]).float(), base)
+    assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2]) and not torch.equal(outs[0], outs[2])
+    assert all(errs[1, n] < errs[2, n] for n in ids), "the activation-side fold must be closer to the reference than the weight-side one"
+    assert torch.equal(fullA.encode_text(ids["hoi600"]).float(), outs[1])
     fullA.truncate_text = True
 
 
 def test_feature_sampler_with_folded_text_layernorm(fullA, g0):
-    """FeatureSampler(fold_text_layernorm=True) runs the HICO loop with option text_ln_fold for the duration of sample() and puts the
-    default back: same latents -> features within the tolerance of the default path's, option off again afterwards."""
+    """FeatureSampler(text_ln_fold=2) runs the HICO loop with that setting of the library option for the duration of sample() and puts
+    the default back: same latents -> features within the tolerance of the default path's, default again afterwards."""
     from hoigen_amd.generation import hico_sampler
     s = hico_sampler(fullA, g0["_classnames"])
     gen = torch.Generator(device=dev()).manual_seed(11)
     base, tgt = s.sample(iterations=2, generator=gen, batch_iters=2)
-    s.fold_text_layernorm = True
+    s.text_ln_fold = 2
     gen = torch.Generator(device=dev()).manual_seed(11)
     fold, tgt2 = s.sample(iterations=2, generator=gen, batch_iters=2)
     assert torch.equal(tgt, tgt2) and base.shape == (2 * 1800, 512)
     assert not torch.equal(base, fold), "the flag did not change the executed path"
     # (two realisations of the fp16 roundings of 12 blocks + mlp_net, each within 1e-3 of the reference's: 9.2e-4 apart, worst row 1.3e-3)
     check(fold, base.cpu().numpy(), tol=2e-3, what="generated features, folded text LayerNorm vs default")
-    s.fold_text_layernorm = False
+    s.text_ln_fold = None
     gen = torch.Generator(device=dev()).manual_seed(11)
     again, _ = s.sample(iterations=2, generator=gen, batch_iters=2)
     assert torch.equal(again, base), "the default path did not come back"

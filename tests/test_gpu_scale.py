@@ -162,39 +162,56 @@ def test_variant_c_600_crops_with_priors_equals_chunks():
 
 def test_text_700_prompts_equals_chunks(fullA, g0):
     """encode_text across a pass boundary of the text tower (65 536 rows per pass, equal passes): 1 000 prompts x 77 tokens = two passes
-    of 500 (the 600 HOI + 81 object + 117 verb + 202 CoOp prompts); truncated to their 13-16 tokens they are one pass."""
+    of 500 (the 600 HOI + 81 object + 117 verb + 202 CoOp prompts); truncated to their 13-16 tokens they are one pass.  A prompt's bits
+    depend on the PATH its call takes, never on its neighbours: with the LayerNorms folded (text_ln_fold 1, the default, and 2) every
+    call of at least 512 rows takes the folded path and smaller calls the separate kernels - as in the vision tower - so pieces of >= 512
+    rows equal the whole call bit for bit, a smaller piece equals the separate-kernel result bit for bit and the folded one within the
+    parity tolerance; with text_ln_fold = 0 every piece equals the whole call."""
     rows = g0["hoi600"]["ids"] + g0["obj81"]["ids"] + g0["verb117"]["ids"] + g0["coop_hoi600"]["ids"][:202]
     ids = np.zeros((len(rows), 77), np.int64)
     for i, r in enumerate(rows):
         ids[i, :len(r)] = r
     ids = torch.from_numpy(ids).to(dev())
     assert ids.shape[0] == 1000
-    # (option mlp_fused: a row's MLP runs as the one kernel or as two GEMMs depending on where it falls in its pass - the bits of a row
-    # depend on that path, never on its neighbours: each path is held to bit-equality on its own, the default against both)
+    longest = int(ids.argmax(dim=-1).argmax())
+
+    def piece(lo, hi, trunc):
+        # truncation length = max(EOT)+1 over the CALL: give the pieces the same length by keeping the longest prompt of the set in each
+        sel = torch.arange(lo, hi, device=ids.device)
+        if trunc and not (lo <= longest < hi):
+            sel = torch.cat([sel, torch.tensor([longest], device=ids.device)])
+        return fullA.encode_text(ids[sel])[: hi - lo]
+
+    # (option mlp_fused lives in the separate-LayerNorm path: a row's MLP runs as the one kernel or as two GEMMs depending on where it
+    # falls in its pass - each path is held to bit-equality on its own, the default against both)
     wholes = {}
     try:
-        for mlp in (0, 2, 1):
+        for fold, mlp in ((0, 0), (0, 2), (0, 1), (1, 0), (2, 0)):
+            fullA.set_option("text_ln_fold", fold)
             fullA.set_option("mlp_fused", mlp)
             for trunc in (False, True):
                 fullA.truncate_text = trunc
-                whole = wholes[mlp, trunc] = fullA.encode_text(ids)
-                if mlp == 1:
+                whole = wholes[fold, mlp, trunc] = fullA.encode_text(ids)
+                if (fold, mlp) == (0, 1):
                     for other in (0, 2):
-                        err = float((whole.float() - wholes[other, trunc].float()).norm() / wholes[other, trunc].float().norm())
+                        ref = wholes[0, other, trunc].float()
+                        err = float((whole.float() - ref).norm() / ref.norm())
                         assert err < 9e-4, f"mlp_fused=1 vs {other}, truncate={trunc}: {err:.2e}"      # (two realisations of 12 blocks of fp16 roundings, each ~6.5e-4 from the reference)
                     continue
-                # truncation length = max(EOT)+1 over the CALL: give the pieces the same length by keeping the longest
-                # prompt of the whole set in every piece
-                longest = int(ids.argmax(dim=-1).argmax())
-                for lo, hi in ((0, 500), (500, 1000), (490, 510), (0, 640)):
-                    sel = torch.arange(lo, hi, device=ids.device)
-                    if trunc and not (lo <= longest < hi):
-                        sel = torch.cat([sel, torch.tensor([longest], device=ids.device)])
-                    part = fullA.encode_text(ids[sel])[: hi - lo]
-                    assert torch.equal(part, whole[lo:hi]), f"prompts [{lo},{hi}) truncate={trunc} mlp_fused={mlp}"
-        assert not torch.equal(wholes[0, False], wholes[2, False]), "option mlp_fused did not change the executed path"
+                for lo, hi in ((0, 500), (500, 1000), (480, 530), (0, 640)):      # (50 prompts x 13 tokens = 650 rows: the folded path)
+                    assert torch.equal(piece(lo, hi, trunc), whole[lo:hi]), f"prompts [{lo},{hi}) truncate={trunc} text_ln_fold={fold} mlp_fused={mlp}"
+                small = piece(490, 510, trunc)      # 20 prompts: 273 rows truncated (the separate kernels whatever the option), 1 540 at 77 tokens
+                if fold == 0 or not trunc:
+                    assert torch.equal(small, whole[490:510]), f"prompts [490,510) truncate={trunc} text_ln_fold={fold} mlp_fused={mlp}"
+                else:
+                    assert torch.equal(small, wholes[0, 0, trunc][490:510]), "a call below 512 rows must take the separate-LayerNorm path"
+                    err = float((small.float() - whole[490:510].float()).norm() / whole[490:510].float().norm())
+                    assert err < 1e-3, f"small call vs folded whole call: {err:.2e}"
+        assert not torch.equal(wholes[0, 0, False], wholes[0, 2, False]), "option mlp_fused did not change the executed path"
+        assert not torch.equal(wholes[0, 0, False], wholes[1, 0, False]) and not torch.equal(wholes[1, 0, False], wholes[2, 0, False])
     finally:
         fullA.set_option("mlp_fused", 0)
+        fullA.set_option("text_ln_fold", 1)
         fullA.truncate_text = True
 
 
