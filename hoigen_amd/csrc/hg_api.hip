@@ -133,7 +133,7 @@ struct hg_ctx {
     Cache cache[HG_MAX_CACHE_SLOTS];
     // workspace (grow-only)
     Buf x, h, qkv, att, fc, head16, tok32, small, i32, ad32, ad16, adkv, mr, mu, muc, stats, pre, pretab, cx, ca, ch, cf, cq;
-    Buf hg;              // folded path with the LayerNorm weight in the activation copy h (text tower): the stream's unscaled hi half, fragment order
+    Buf hg;              // folded path with the LayerNorm weight in the activation copy (text tower): that copy, beside the stream's hi half in h
     Buf att2;            // variant C with the stream as centre + hi + lo: the out-proj operand [att | e] beside the in_proj one [x16 | e]
     Buf zpark;           // hg_vae_fused.hip: the encoder's first z half as fp16 fragments, per wave
     Buf xlo;             // low half of the residual stream while it is held as centre + hi + lo (GemmArgs::hl)
@@ -704,9 +704,9 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         else {
             if (kmode.size() && kmode[0] == 2) kmode[0] = 0;      // rowstats_cast writes dense rows
             if (gamma_act && !adapters) {
-                int rc2 = ensure(c, c->hg, gemm_lo_bytes(M, D));      // (fp16 pieces: 128 x 256 x 2 B per tile)
+                int rc2 = ensure(c, c->hg, rup(M, 256) * (size_t)D * 2);
                 if (rc2) return rc2;
-                HG_HIP(launch_rowstats_cast(x, h, mr, mu, M, D, s, muc, blocks[0].ln1_w));
+                HG_HIP(launch_rowstats_cast(x, (half_t*)c->hg.p, mr, mu, M, D, s, muc, blocks[0].ln1_w));
             } else {
                 HG_HIP(launch_rowstats_cast(x, h, mr, mu, M, D, s, muc));
             }
@@ -757,13 +757,17 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         return kmode[i] == 2 && hilo_c && c->opt_qkv_attn_c && c->vit.adapters[i].fold[ac->priors ? 0 : 1].wp_qcat != nullptr &&
                qkv_attn_ok(n_seq, L, D, heads, D + 64, D + 64);
     };
-    // gs (text tower): the LayerNorm weight rides in the activation copy h (GemmArgs::gamma), the consumers multiply by the layer's own
-    // fp16 weights: no second rounding of W * gamma.  The stream's unscaled hi half then lives in c->hg, in fragment order
+    // gs (text tower): the LayerNorm weight rides in the activation copy (GemmArgs::gamma), the consumers multiply by the layer's own
+    // fp16 weights: no second rounding of W * gamma.  a_ln = where the next consumer finds that copy: c->hg behind a producer that keeps
+    // h as the stream's hi half (hl 1, 2), h itself otherwise
     const bool gs = gamma_act && fuse && !adapters && pre_w == nullptr;
+    half_t* const hg = gs ? (half_t*)c->hg.p : nullptr;
+    half_t* a_ln = gs ? hg : h;
     auto gs_args = [&](GemmArgs& g, const float* gamma) {
         if (!gs) return;
         g.gamma = gamma;
-        g.hif = (half_t*)c->hg.p;
+        if (g.hl == 1 || g.hl == 2) { g.out3 = hg; g.ld3 = D; a_ln = hg; }
+        else a_ln = h;
     };
     int rln_i = 0;                  // index of the next LayerNorm-emitting residual GEMM
     bool x_is_hilo = false;         // the stream currently lives in (h, xlo, muc), not in x
@@ -814,7 +818,7 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
             HG_HIP(launch_qkv_attn(qa, s));
         } else if (fuse) {
             g.W = b.wf_qkv + qoff * D; g.bias = b.bf_qkv + qoff; g.cs = b.cs_qkv + qoff; g.mr = mr;
-            if (gs) { g.W = b.w_qkv + qoff * D; g.cs = b.csg_qkv + qoff; }
+            if (gs) { g.A = a_ln; g.W = b.w_qkv + qoff * D; g.cs = b.csg_qkv + qoff; }
             HG_HIP(gemm(c, EPI_LN_BIAS_F16, g, s));
         } else {
             HG_HIP(launch_layernorm_f16(x, b.ln1_w, b.ln1_b, h, M, D, nullptr, 0, 1, s));
@@ -875,7 +879,7 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         if (fuse) {
             g.W = b.wf_fc; g.bias = b.bf_fc; g.cs = b.cs_fc; g.mr = mr;
             if (hilo_c) { g.A = att; g.lda = D + 64; }
-            if (gs) { g.W = b.w_fc; g.cs = b.csg_fc; }
+            if (gs) { g.A = a_ln; g.W = b.w_fc; g.cs = b.csg_fc; }
             HG_HIP(gemm(c, EPI_LN_BIAS_QGELU_F16, g, s));
         } else {
             HG_HIP(launch_layernorm_f16(x, b.ln2_w, b.ln2_b, h, M, D, nullptr, 0, 1, s));

@@ -48,8 +48,9 @@ namespace hg {
 // GS (EPI_RESID_LN_F32 only; GemmArgs::gamma): the copy the next GEMM reads is fp16((x' - mu) * gamma[n]) - the next LayerNorm's weight
 // rides in the ACTIVATION copy, so that the consuming GEMM multiplies by the layer's own fp16 weights (as the reference does) and not by
 // a re-rounded fp16(W * gamma): the folded text tower's excess error against the reference was that second rounding
-// (tests/test_gpu_text_fold_study.py).  out2 is always that scaled copy; where the stream is held as hi + lo its unscaled
-// hi then lives in `hif`, in the tile-fragment order of lo (whole 16-byte pieces per lane; only this kernel's epilogue reads it).
+// (tests/test_gpu_text_fold_study.py).  Where the stream leaves as hi + lo (HL 1, 2) the unscaled hi stays the stream's half in out2 and
+// the scaled copy goes to out3 (8 more stores per wave and tile); where it leaves as fp32 (HL 0, 3) out2 itself is the scaled copy.
+// (The unscaled hi in fragment order beside lo, with out2 always the scaled copy, was built too: the same time, six spilled registers.)
 template <int EPI, int HL = 0, bool GS = false>
 __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int tiles_n, const int n_tiles,
                                                      const unsigned a_bytes, const int mode, const int gsz) {
@@ -328,9 +329,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
             return p.lo + ((((size_t)tm_ * tiles_n + tn_) * 8 + wave) * 8 + (ha * 4 + hb * 2 + g2)) * (HG_LO8 ? 256 : 512) +
                    lane * (HG_LO8 ? 4 : 8);
         };
-        auto hif_ptr = [&](int tm_, int tn_, int ha, int hb, int g2) {      // (GS) hi piece: 64 lanes x 16 B
-            return p.hif + ((((size_t)tm_ * tiles_n + tn_) * 8 + wave) * 8 + (ha * 4 + hb * 2 + g2)) * 512 + lane * 8;
-        };
         // One K-tile.  KIND: 0 middle, 1 first of a tile (the previous epilogue's stores may be pending), 2 / 3 / 4 the
         // third-to-last, second-to-last and last K-tile of a tile: only there the refills (A at distance 2, W at
         // distance 3) and the waits depend on whether another tile follows.  K >= 256 keeps the kinds distinct.
@@ -355,11 +353,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                         for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
                             for (int g2 = 0; g2 < 2; ++g2) {
-                                if constexpr (GS)      // the unscaled hi half in fragment order: this lane's two row tiles side by side
-                                    xhi[ha][hb][g2] = *reinterpret_cast<const u32x4_hl*>(hif_ptr(tm, tn, ha, hb, g2));
-                                else
-                                    xhi[ha][hb][g2] = *reinterpret_cast<const u32x4_hl*>(
-                                        p.out2 + (size_t)mp * p.ld2 + n0 + hb * 128 + wn * 32 + g2 * 16 + 4 * (qq & ~1));
+                                xhi[ha][hb][g2] = *reinterpret_cast<const u32x4_hl*>(
+                                    p.out2 + (size_t)mp * p.ld2 + n0 + hb * 128 + wn * 32 + g2 * 16 + 4 * (qq & ~1));
                                 if constexpr (HG_LO8) {
                                     typedef unsigned u32x2_hl __attribute__((ext_vector_type(2)));
                                     const u32x2_hl l8 = *reinterpret_cast<const u32x2_hl*>(lo_ptr(tm, tn, ha, hb, g2));
@@ -498,15 +493,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
 #pragma unroll
                         for (int g2 = 0; g2 < 2; ++g2) {
                             const u32x4_hl o = xhi[ha][hb][g2], l = xlo[ha][hb][g2];
-                            if constexpr (GS) {      // (fragment order: no exchange)
-                                hin[0][hb][g2] = __builtin_bit_cast(half4, u32x2{o[0], o[1]});
-                                hin[1][hb][g2] = __builtin_bit_cast(half4, u32x2{o[2], o[3]});
-                            } else {
-                                const auto s0 = __builtin_amdgcn_permlane16_swap(o[0], o[2], false, false);
-                                const auto s1 = __builtin_amdgcn_permlane16_swap(o[1], o[3], false, false);
-                                hin[0][hb][g2] = __builtin_bit_cast(half4, u32x2{(unsigned)s0[0], (unsigned)s1[0]});
-                                hin[1][hb][g2] = __builtin_bit_cast(half4, u32x2{(unsigned)s0[1], (unsigned)s1[1]});
-                            }
+                            const auto s0 = __builtin_amdgcn_permlane16_swap(o[0], o[2], false, false);
+                            const auto s1 = __builtin_amdgcn_permlane16_swap(o[1], o[3], false, false);
+                            hin[0][hb][g2] = __builtin_bit_cast(half4, u32x2{(unsigned)s0[0], (unsigned)s1[0]});
+                            hin[1][hb][g2] = __builtin_bit_cast(half4, u32x2{(unsigned)s0[1], (unsigned)s1[1]});
                             if constexpr (HG_LO8) {
 #pragma unroll
                                 for (int f = 0; f < 2; ++f) {
@@ -622,16 +612,17 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
 #pragma unroll
                     for (int g2 = 0; g2 < 2; ++g2) {
                         const int nb = n0 + hb * 128 + wn * 32 + g2 * 16;
-                        // (GS with the stream as hi + lo: the row-major copy is the scaled one, the unscaled hi goes out in fragment order)
-                        const u32x2 ux = __builtin_bit_cast(u32x2, (GS && OUT_HL) ? g16[0][hb][g2] : h16[0][hb][g2]);
-                        const u32x2 uy = __builtin_bit_cast(u32x2, (GS && OUT_HL) ? g16[1][hb][g2] : h16[1][hb][g2]);
+                        const u32x2 ux = __builtin_bit_cast(u32x2, h16[0][hb][g2]), uy = __builtin_bit_cast(u32x2, h16[1][hb][g2]);
                         const auto s0 = __builtin_amdgcn_permlane16_swap(ux[0], uy[0], false, false);
                         const auto s1 = __builtin_amdgcn_permlane16_swap(ux[1], uy[1], false, false);
                         const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
                         if (INTERIOR || m < p.M) *reinterpret_cast<u32x4*>(out2 + (size_t)m * p.ld2 + nb + 4 * (q & ~1)) = o;
-                        if constexpr (GS && OUT_HL) {
-                            const u32x2 hx = __builtin_bit_cast(u32x2, h16[0][hb][g2]), hy = __builtin_bit_cast(u32x2, h16[1][hb][g2]);
-                            *reinterpret_cast<u32x4*>(hif_ptr(tm, tn, ha, hb, g2)) = u32x4{hx[0], hx[1], hy[0], hy[1]};
+                        if constexpr (GS && OUT_HL) {      // the scaled copy beside the stream's hi half
+                            const u32x2 gx = __builtin_bit_cast(u32x2, g16[0][hb][g2]), gy = __builtin_bit_cast(u32x2, g16[1][hb][g2]);
+                            const auto t0 = __builtin_amdgcn_permlane16_swap(gx[0], gy[0], false, false);
+                            const auto t1 = __builtin_amdgcn_permlane16_swap(gx[1], gy[1], false, false);
+                            const u32x4 og = {t0[0], t1[0], t0[1], t1[1]};
+                            if (INTERIOR || m < p.M) *reinterpret_cast<u32x4*>(p.out3 + (size_t)m * p.ld3 + nb + 4 * (q & ~1)) = og;
                         }
                         if constexpr (OUT_HL) {      // the remainder: this lane's two row tiles side by side, the wave's piece contiguous
                             if constexpr (HG_LO8) {
@@ -783,8 +774,8 @@ hipError_t launch_gemm_ring2(int epi, const GemmArgs& a_in, hipStream_t s) {
         case EPI_SCALE_RESID_F32: return launch_ring2_t<EPI_SCALE_RESID_F32>(a, s);
         case EPI_RESID_LN_F32:
             if (a.hl && (!a.lo || !a.mu || ((a.hl == 2 || a.hl == 3) && !a.muc))) return hipErrorInvalidValue;      // (the hi half lives at out2 with row stride ld2: any)
-            if (a.gamma) {      // the copy scaled by the next LayerNorm's weight (hl != 0: the stream's hi half lives in hif)
-                if (a.hl && !a.hif) return hipErrorInvalidValue;
+            if (a.gamma) {      // the copy scaled by the next LayerNorm's weight (hl 1, 2: in out3 beside the stream's hi half in out2)
+                if ((a.hl == 1 || a.hl == 2) && (!a.out3 || a.ld3 < a.N || (a.ld3 % 8))) return hipErrorInvalidValue;
                 switch (a.hl) {
                     case 0: return launch_ring2_t<EPI_RESID_LN_F32, 0, true>(a, s);
                     case 1: return launch_ring2_t<EPI_RESID_LN_F32, 1, true>(a, s);

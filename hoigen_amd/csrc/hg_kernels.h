@@ -77,11 +77,11 @@ struct GemmArgs {
     half_t* lo = nullptr;
     const float* muc = nullptr;
     // EPI_RESID_LN_F32 (gemm_ring2): gamma [N] = the NEXT LayerNorm's weight, multiplied into the copy the next GEMM reads -
-    // out2 = fp16((x - mu) * gamma) - so that GEMM runs on the layer's own fp16 weights with cs[n] = sum_k gamma[k] W[n][k] (fold_ln's csg).
-    // Where the stream is held as hi + lo (hl != 0) its unscaled hi half then lives in `hif` (gemm_lo_bytes(M, N) * 2 bytes, tile-fragment
-    // order like lo: written by hl 1 / 2, read by hl 2 / 3) instead of being that copy.
+    // fp16((x - mu) * gamma) - so that GEMM runs on the layer's own fp16 weights with cs[n] = sum_k gamma[k] W[n][k] (fold_ln's csg).
+    // hl 0 / 3: out2 is that scaled copy; hl 1 / 2: out2 stays the stream's unscaled hi half and the scaled copy goes to out3 (row stride ld3)
     const float* gamma = nullptr;
-    half_t* hif = nullptr;
+    half_t* out3 = nullptr;
+    int ld3 = 0;
 };
 // bytes of the `lo` buffer for M rows x N columns (whole 128 x 256 tiles)
 inline size_t gemm_lo_bytes(int M, int N) { return (size_t)((M + 127) / 128) * (N / 256) * 65536; }
