@@ -550,13 +550,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ring2(const GemmArgs p, const int
                             // converted once and read back from its packed form)
                             typedef float f32x2 __attribute__((ext_vector_type(2)));
                             const f32x2 mu2 = {muv[ha][f], muv[ha][f]};
+                            f32x4 gm4 = f32x4{1.f, 1.f, 1.f, 1.f};
+                            if constexpr (GS) gm4 = *reinterpret_cast<const f32x4*>(smem + BIAS_OFF + p.N * 4 + n * 4);      // (one 16-byte read per four columns)
                             float rem[4];
 #pragma unroll
                             for (int e2 = 0; e2 < 2; ++e2) {
                                 const f32x2 d = f32x2{v[hb][g2][2 * e2], v[hb][g2][2 * e2 + 1]} - mu2;
                                 half2v hh = __builtin_convertvector(d, half2v);
                                 if constexpr (GS) {
-                                    const f32x2 gm2 = *reinterpret_cast<const f32x2*>(smem + BIAS_OFF + p.N * 4 + (n + 2 * e2) * 4);
+                                    const f32x2 gm2 = f32x2{gm4[2 * e2], gm4[2 * e2 + 1]};
                                     const half2v hg = __builtin_convertvector(d * gm2, half2v);
                                     if constexpr (OUT_HL) {
                                         g16[f][hb][g2][2 * e2] = hg[0];
