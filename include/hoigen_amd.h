@@ -235,11 +235,12 @@ int hg_vae_loss(hg_ctx*, const float* recon, const float* x, const float* mean, 
  * Per context; the environment only supplies the initial values at hg_create (variable in brackets).  Keys:
  *   "last_block_row0" [HG_LAST_BLOCK_ROW0] 1: towers without token outputs run their LAST block on the one row per sequence
  *                      that reaches the output (class / EOT token); 0: on every row, like the reference
- *   "ln_fuse"         [HG_LN_FUSE]         1: LayerNorm folded into the GEMMs (vision tower, M >= 512); 0: separate kernels
+ *   "ln_fuse"         [HG_LN_FUSE]         1: LayerNorm folded into the GEMMs (both towers, calls of at least 512 rows; the text tower's
+ *                      form: "text_ln_fold"); 0: separate LayerNorm kernels everywhere
  *   "adapter_fuse"    [HG_ADAPTER_FUSE]    1: ... also around the instance adapters of variant C
  *   "adapter_fold"    [HG_ADAPTER_FOLD]    1: adapter update folded into the block's own GEMMs; 0: separate up_proj GEMM
- *   "stream_hilo"     [HG_STREAM_HILO]     1: between the LayerNorm-folded blocks of variant A (and of variant C when every block's adapter is
- *                      folded into its GEMMs) the residual stream is held as
+ *   "stream_hilo"     [HG_STREAM_HILO]     1: between the LayerNorm-folded blocks of variant A, of the text tower (and of variant C when every
+ *                      block's adapter is folded into its GEMMs) the residual stream is held as
  *                      centre + hi + lo (the centred fp16 copy the GEMMs read + its remainder as bf8; fp16 in a -DHG_LO8=0 build:
  *                      read-only option "stream_lo_bits" = 8 / 16); 0: as fp32 throughout
  *   "qkv_attn"        [HG_QKV_ATTN]        1: in the LayerNorm-folded blocks of the vision tower in_proj and attention run as ONE kernel
