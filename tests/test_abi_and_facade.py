@@ -187,3 +187,21 @@ def test_non_vit_checkpoint_rejected():
     del sd["visual.proj"]
     with pytest.raises(NotImplementedError):
         build_model(sd)
+
+
+def test_every_option_is_documented_and_every_documented_option_exists():
+    """include/hoigen_amd.h lists the behaviour options (key + environment variable); hg_set_option / hg_get_option / hg_create in
+    hoigen_amd/csrc/hg_api.hip implement them.  The two lists and the environment names must agree (documentation drift was a review
+    finding of round 4)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "hoigen_amd.h")).read()
+    api = open(os.path.join(root, "hoigen_amd", "csrc", "hg_api.hip")).read()
+    documented = dict(re.findall(r'^ \*   "([a-z_0-9]+)"\s+\[(HG_[A-Z_0-9]+)\]', hdr, flags=re.M))
+    set_keys = set(re.findall(r'k == "([a-z_0-9]+)"', api[api.index("int hg_set_option("):api.index("int hg_get_option(")]))
+    get_keys = set(re.findall(r'k == "([a-z_0-9]+)"', api[api.index("int hg_get_option("):api.index("void hg_destroy(")]))
+    env = dict((k, e) for e, k in re.findall(r'\{"(HG_[A-Z_0-9]+)", "([a-z_0-9]+)"\}', api))
+    assert set(documented) == set_keys, (sorted(set(documented) ^ set_keys))
+    assert set_keys <= get_keys and get_keys - set_keys <= {"stream_lo_bits"}      # (read-only: how the build holds the low half)
+    assert env == documented, {k: (env.get(k), documented.get(k)) for k in set(env) | set(documented) if env.get(k) != documented.get(k)}
+
