@@ -137,6 +137,7 @@ struct hg_ctx {
     Buf att2;            // variant C with the stream as centre + hi + lo: the out-proj operand [att | e] beside the in_proj one [x16 | e]
     Buf zpark;           // hg_vae_fused.hip: the encoder's first z half as fp16 fragments, per wave
     Buf xlo;             // low half of the residual stream while it is held as centre + hi + lo (GemmArgs::hl)
+    Buf pair_ready;      // hg_mlp_pair.hip: ready counters [blocks][256-row panels], zeroed at the start of every tower pass
     int max_chunk_img = 256;
     int text_rows_budget = 65536;      // rows (prompts x executed tokens) per pass of the text tower (text_chunk_prompts)
     int max_chunk_rows = 32768;
@@ -161,7 +162,14 @@ struct hg_ctx {
                                  // where a call leaves a remainder (600 prompts x 77 tokens: 5.47 -> 5.66 ms)
     int opt_vae_fused = 1;       // CoOp-VAE Encoder -> reparameterise -> Generator as ONE kernel (hg_vae_fused.hip) for the rows that fill
                                  // whole rounds of 128-row items over the CUs (the rest: the GEMM path); 2: every row; 0: GEMM path only
+    int opt_mlp_pair = 0;        // c_fc -> QuickGELU -> c_proj of a LayerNorm-folded block as ONE persistent launch with per-row-panel ready
+                                 // counters between its tiles (hg_mlp_pair.hip; vision tower, variant A); bit-identical to the two launches
+    int opt_mlp_pair_chunk = 8;  // ... 256-row panels of an XCD per chunk
+    int opt_mlp_pair_fc_slots = 30;  // ... workgroups per XCD that run c_fc tiles (the rest start with c_proj)
     int n_cu = 256;
+    // sticky device->host flag (host-mapped): a hand-off wait inside the MLP pair kernel gave up (a workgroup of its grid never became
+    // resident); the call in flight returned garbage, the next tower call reports HG_ERR_HIP
+    int32_t* pair_err = nullptr;
     // sticky device->host flag (host-mapped): set by clamp_eot when a caller-supplied text truncation was shorter than
     // max(EOT)+1 (a stale host memo); reported as HG_ERR_INVALID by the next text call
     int32_t* eot_flag = nullptr;
@@ -634,6 +642,12 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
     const int M = n_seq * L;
     const bool row0_env = c->opt_row0 != 0;
     if (row0_out) *row0_out = nullptr;
+    if (c->pair_err && *(volatile int32_t*)c->pair_err) {
+        *(volatile int32_t*)c->pair_err = 0;
+        return fail(c, HG_ERR_HIP, "a hand-off wait inside the MLP pair kernel of a previous call timed out (a workgroup of its grid never "
+                                   "became resident): that call's outputs are invalid; set option mlp_pair = 0 if this device cannot "
+                                   "hold one workgroup per compute unit");
+    }
     float* x = (float*)c->x.p;
     half_t* h = (half_t*)c->h.p;
     half_t* qkv = (half_t*)c->qkv.p;
@@ -769,6 +783,15 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         if (g.hl == 1 || g.hl == 2) { g.out3 = hg; g.ld3 = D; a_ln = hg; }
         else a_ln = h;
     };
+    // c_fc and c_proj of a block as ONE persistent launch (option mlp_pair, hg_mlp_pair.hip): LayerNorm-folded blocks without adapters and
+    // without the activation-side gamma, where c_proj is a LayerNorm-emitting residual GEMM (every block but the tower's last)
+    const int pair_panels = (int)rup(mlp_pair_ready_words(M), 64);      // words per block: the census, then a counter per 256-row panel
+    const bool pair_on = fuse && !adapters && !gs && c->opt_mlp_pair && c->pair_err && blocks.size() > 1;
+    if (pair_on) {
+        int rc = ensure(c, c->pair_ready, blocks.size() * (size_t)pair_panels * 4);
+        if (rc) return rc;
+        HG_HIP(hipMemsetAsync(c->pair_ready.p, 0, blocks.size() * (size_t)pair_panels * 4, s));
+    }
     int rln_i = 0;                  // index of the next LayerNorm-emitting residual GEMM
     bool x_is_hilo = false;         // the stream currently lives in (h, xlo, muc), not in x
     auto rln_args = [&](GemmArgs& g) {
@@ -876,11 +899,25 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         g = GemmArgs{};
         g.A = h; g.lda = D; g.out = fc; g.ldc = 4 * D; g.M = M; g.N = 4 * D; g.K = D;
         int mlp_done = 0;      // leading rows whose MLP ran as the one kernel (separate-LayerNorm path, width 512)
+        GemmArgs pq{};         // option mlp_pair: the c_proj arguments, built ahead of c_fc (pq_built), and whether the pair kernel took both
+        bool pq_built = false, paired = false;
         if (fuse) {
             g.W = b.wf_fc; g.bias = b.bf_fc; g.cs = b.cs_fc; g.mr = mr;
             if (hilo_c) { g.A = att; g.lda = D + 64; }
             if (gs) { g.A = a_ln; g.W = b.w_fc; g.cs = b.csg_fc; }
-            HG_HIP(gemm(c, EPI_LN_BIAS_QGELU_F16, g, s));
+            if (pair_on && i + 1 < blocks.size()) {
+                pq.A = fc; pq.lda = 4 * D; pq.W = b.w_proj; pq.bias = b.b_proj; pq.out = x; pq.ldc = D; pq.M = M; pq.N = D; pq.K = 4 * D;
+                pq.out2 = h_of(i + 1); pq.ld2 = ldh_of(i + 1); pq.stats = stats; pq.stats_ld = sld; pq.mu = mu;
+                rln_args(pq);
+                pq_built = true;
+                if (mlp_pair_ok(g, pq, c->n_cu)) {
+                    ProfScope ps(c, s, HG_PROF_MLP_PAIR, M, 4 * D, D);
+                    HG_HIP(launch_mlp_pair(g, pq, (unsigned*)c->pair_ready.p + i * (size_t)pair_panels, c->pair_err,
+                                           c->opt_mlp_pair_chunk, c->opt_mlp_pair_fc_slots, c->n_cu, s));
+                    paired = true;
+                }
+            }
+            if (!paired) HG_HIP(gemm(c, EPI_LN_BIAS_QGELU_F16, g, s));
         } else {
             HG_HIP(launch_layernorm_f16(x, b.ln2_w, b.ln2_b, h, M, D, nullptr, 0, 1, s));
             // Width 512 (the text tower): x += W_proj quickgelu(W_fc h + b_fc) + b_proj as ONE kernel for the leading rows that fill
@@ -907,10 +944,14 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         g.A = fc; g.lda = 4 * D; g.W = b.w_proj; g.bias = b.b_proj; g.out = x + (size_t)mlp_done * D; g.ldc = D; g.M = M - mlp_done; g.N = D;
         g.K = 4 * D;
         if (fuse && i + 1 < blocks.size()) {      // the last block is followed by ln_post / ln_final on selected rows
-            g.out2 = h_of(i + 1); g.ld2 = ldh_of(i + 1); g.stats = stats; g.stats_ld = sld; g.mu = mu;
-            rln_args(g);
-            gs_args(g, blocks[i + 1].ln1_w);
-            HG_HIP(gemm(c, EPI_RESID_LN_F32, g, s));
+            if (pq_built) {
+                g = pq;
+            } else {
+                g.out2 = h_of(i + 1); g.ld2 = ldh_of(i + 1); g.stats = stats; g.stats_ld = sld; g.mu = mu;
+                rln_args(g);
+                gs_args(g, blocks[i + 1].ln1_w);
+            }
+            if (!paired) HG_HIP(gemm(c, EPI_RESID_LN_F32, g, s));
             HG_HIP(launch_finalize_stats(stats, mr, mu, M, sld, 64, s, muc));
         } else {
             HG_HIP(gemm(c, EPI_BIAS_RESID_F32, g, s));
@@ -1038,12 +1079,16 @@ hg_ctx* hg_create(int device) {
         else c->eot_flag = nullptr;
         if (hipMalloc((void**)&c->eot_flag_dev, 64) != hipSuccess) c->eot_flag_dev = nullptr;
         else (void)hipMemset(c->eot_flag_dev, 0, 64);
+        if (hipHostMalloc((void**)&c->pair_err, 64, hipHostMallocMapped) == hipSuccess && c->pair_err) *c->pair_err = 0;
+        else c->pair_err = nullptr;
     }
     struct { const char* env; const char* key; } init[] = {{"HG_CHUNK_ROWS", "chunk_rows"}, {"HG_LAST_BLOCK_ROW0", "last_block_row0"},
                                                            {"HG_LN_FUSE", "ln_fuse"}, {"HG_ADAPTER_FUSE", "adapter_fuse"},
                                                            {"HG_ADAPTER_FOLD", "adapter_fold"}, {"HG_STREAM_HILO", "stream_hilo"},
                                                            {"HG_QKV_ATTN", "qkv_attn"}, {"HG_QKV_ATTN_MIN_SEQ", "qkv_attn_min_seq"},
-                                                           {"HG_QKV_ATTN_GSZ", "qkv_attn_gsz"}, {"HG_QKV_ATTN_C", "qkv_attn_c"}, {"HG_TEXT_LN_FOLD", "text_ln_fold"}, {"HG_VAE_FUSED", "vae_fused"}, {"HG_MLP_FUSED", "mlp_fused"}};
+                                                           {"HG_QKV_ATTN_GSZ", "qkv_attn_gsz"}, {"HG_QKV_ATTN_C", "qkv_attn_c"}, {"HG_TEXT_LN_FOLD", "text_ln_fold"}, {"HG_VAE_FUSED", "vae_fused"}, {"HG_MLP_FUSED", "mlp_fused"},
+                                                           {"HG_MLP_PAIR", "mlp_pair"},
+                                                           {"HG_MLP_PAIR_CHUNK", "mlp_pair_chunk"}, {"HG_MLP_PAIR_FC_SLOTS", "mlp_pair_fc_slots"}};
     for (auto& o : init)
         if (const char* e = getenv(o.env)) (void)hg_set_option(c, o.key, atoi(e));      // (out-of-range values are ignored)
     c->err.clear();
@@ -1083,6 +1128,15 @@ int hg_set_option(hg_ctx* c, const char* key, int value) {
     } else if (k == "mlp_fused") {
         if (value < 0 || value > 2) return fail(c, HG_ERR_INVALID, "mlp_fused must be 0, 1 or 2 (got %d)", value);
         c->opt_mlp_fused = value;
+    } else if (k == "mlp_pair") {
+        if (value < 0 || value > 1) return fail(c, HG_ERR_INVALID, "mlp_pair must be 0 or 1 (got %d)", value);
+        c->opt_mlp_pair = value;
+    } else if (k == "mlp_pair_chunk") {
+        if (value < 1 || value > 64) return fail(c, HG_ERR_INVALID, "mlp_pair_chunk must be 1 .. 64 (got %d)", value);
+        c->opt_mlp_pair_chunk = value;
+    } else if (k == "mlp_pair_fc_slots") {
+        if (value < 1 || value > 64) return fail(c, HG_ERR_INVALID, "mlp_pair_fc_slots must be 1 .. 64 (got %d)", value);
+        c->opt_mlp_pair_fc_slots = value;
     }
     else return fail(c, HG_ERR_INVALID, "unknown option '%s'", key);
     return HG_OK;
@@ -1105,6 +1159,9 @@ int hg_get_option(hg_ctx* c, const char* key, int* value) {
     else if (k == "text_ln_fold") *value = c->opt_text_ln_fold;
     else if (k == "vae_fused") *value = c->opt_vae_fused;
     else if (k == "mlp_fused") *value = c->opt_mlp_fused;
+    else if (k == "mlp_pair") *value = c->opt_mlp_pair;
+    else if (k == "mlp_pair_chunk") *value = c->opt_mlp_pair_chunk;
+    else if (k == "mlp_pair_fc_slots") *value = c->opt_mlp_pair_fc_slots;
     else return fail(c, HG_ERR_INVALID, "unknown option '%s'", key);
     return HG_OK;
 }
@@ -1120,12 +1177,13 @@ void hg_destroy(hg_ctx* c) {
     for (auto& m : c->mlp) free_all(m.owned);
     for (auto& m : c->cache) free_all(m.owned);
     Buf* bufs[] = {&c->x, &c->h, &c->qkv, &c->att, &c->fc, &c->head16, &c->tok32, &c->small, &c->i32,
-                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq, &c->xlo, &c->zpark, &c->att2, &c->hg};
+                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq, &c->xlo, &c->zpark, &c->att2, &c->hg, &c->pair_ready};
     for (Buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     if (c->eot_flag) (void)hipHostFree(c->eot_flag);
     if (c->eot_flag_dev) (void)hipFree(c->eot_flag_dev);
+    if (c->pair_err) (void)hipHostFree(c->pair_err);
     delete c;
 }
 
@@ -1469,7 +1527,7 @@ int hg_profile_end(hg_ctx* c, hg_prof_rec* recs, int max_recs, int32_t* n_recs) 
 int hg_workspace_bytes(hg_ctx* c, uint64_t* bytes) {
     if (!c || !bytes) return HG_ERR_INVALID;
     Buf* bufs[] = {&c->x, &c->h, &c->qkv, &c->att, &c->fc, &c->head16, &c->tok32, &c->small, &c->i32,
-                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq, &c->xlo, &c->zpark, &c->att2, &c->hg};
+                   &c->ad32, &c->ad16, &c->adkv, &c->mr, &c->mu, &c->muc, &c->stats, &c->pre, &c->pretab, &c->cx, &c->ca, &c->ch, &c->cf, &c->cq, &c->xlo, &c->zpark, &c->att2, &c->hg, &c->pair_ready};
     uint64_t t = 0;
     for (Buf* b : bufs) t += b->bytes;
     *bytes = t;

@@ -97,6 +97,52 @@ __device__ __forceinline__ float sum_rows(float x) {
     return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
 }
 
+// Tile schedule of the stand-alone persistent kernels (gemm_ring, gemm_ring2).  Tile order (L2 locality): the list is n-group-major
+// (groups of `gsz` column tiles whose W slices fit one XCD's L2 together), m-tile next, column tile inside the group fastest.  XCD x
+// (= blockIdx % 8 under round-robin placement; speed only) owns the contiguous list range [x*T8, (x+1)*T8) and its CUs walk it 'cpx'
+// items per round, so an XCD keeps re-using the same W slices while streaming A panels.  Workgroup's tiles: slot, slot + cpx, ...
+// The kernel bodies (hg_gemm_ring_body.h, hg_gemm_ring2_body.h) only see n_items() / tile() / slack() and the hand-off switches.
+struct RingTileList {
+    static constexpr bool PUBLISH = false, CONSUME = false;      // no tile is handed to / taken from another workgroup of the launch
+    int slot, cpx, my_tiles, max_tiles, gsz, ngf, grem, per_grp;
+    __device__ __forceinline__ RingTileList(int n_tiles, int tiles_n, int gsz_) {
+        const int G = gridDim.x, bid = blockIdx.x;
+        const bool xcd_ok = (G & 7) == 0;
+        cpx = xcd_ok ? (G >> 3) : G;                                   // workgroups per XCD
+        const int T8 = xcd_ok ? (n_tiles + 7) / 8 : n_tiles;            // list items per XCD
+        const int xbase = xcd_ok ? (bid & 7) * T8 : 0;
+        const int xend = (xbase + T8 < n_tiles) ? xbase + T8 : n_tiles;
+        slot = xbase + (xcd_ok ? (bid >> 3) : bid);                    // first list item of this workgroup
+        my_tiles = slot < xend ? (xend - slot + cpx - 1) / cpx : 0;
+        max_tiles = (T8 + cpx - 1) / cpx;
+        gsz = gsz_;
+        const int tiles_m_all = n_tiles / tiles_n;
+        ngf = tiles_n / gsz;
+        grem = tiles_n - ngf * gsz;
+        per_grp = tiles_m_all * gsz;
+    }
+    __device__ __forceinline__ int n_items() const { return my_tiles; }
+    __device__ __forceinline__ int slack() const { return max_tiles - my_tiles; }      // tiles fewer than the fullest workgroups own
+    __device__ __forceinline__ void tile(int r, int& tm, int& tn) const {
+        const int item = slot + r * cpx;
+        if (item < ngf * per_grp) {
+            const int grp = item / per_grp, rr = item - grp * per_grp;
+            tm = rr / gsz;
+            tn = grp * gsz + (rr - tm * gsz);
+        } else {
+            const int rr = item - ngf * per_grp;
+            tm = rr / grem;
+            tn = ngf * gsz + (rr - tm * grem);
+        }
+    }
+    __device__ __forceinline__ int thread_id() const { return threadIdx.x; }
+    // (hand-off hooks of the MLP pair kernel's schedules; never called on this one)
+    __device__ __forceinline__ void publish(int, int) const {}
+    __device__ __forceinline__ unsigned poll_issue(int) const { return 0u; }
+    __device__ __forceinline__ void poll_finish(int, unsigned) const {}
+    __device__ __forceinline__ void poll_blocking(int) const {}
+};
+
 template <int N>
 __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

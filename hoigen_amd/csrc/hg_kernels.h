@@ -100,6 +100,13 @@ bool gemm_ring2_ok(const GemmArgs& a);
 bool gemm_ln_ok(int epi, const GemmArgs& a);
 hipError_t launch_gemm_ring2(int epi, const GemmArgs& a, hipStream_t s);
 hipError_t launch_gemm_simple(int epi, const GemmArgs& a, hipStream_t s);
+// c_fc -> QuickGELU -> c_proj of a block as ONE persistent launch (hg_mlp_pair.hip): fc = the EPI_LN_BIAS_QGELU_F16 GEMM, proj = the
+// EPI_RESID_LN_F32 GEMM that reads fc.out; ready [mlp_pair_ready_words(M)] u32 zeroed on the stream before the launch; err: host-mapped
+// word set when a hand-off wait times out; ch: 256-row panels of an XCD per chunk of the c_fc tile order; fc_slots: workgroups per XCD
+// that run c_fc tiles (of n_cu / 8)
+bool mlp_pair_ok(const GemmArgs& fc, const GemmArgs& proj, int n_cu);
+size_t mlp_pair_ready_words(int M);
+hipError_t launch_mlp_pair(const GemmArgs& fc, const GemmArgs& proj, unsigned* ready, int* err, int ch, int fc_slots, int n_cu, hipStream_t s);
 // two 4-wave workgroups per CU, 128x256 tiles, free-running (hg_gemm_duo.hip): residual GEMMs and fp16/fp32 outputs
 bool gemm_duo_ok(int epi, const GemmArgs& a);
 hipError_t launch_gemm_duo(int epi, const GemmArgs& a, hipStream_t s);

@@ -81,6 +81,40 @@ def test_fused_in_proj_attention_is_bit_identical_inside_encode_image(fullA):
         fullA.visual.set_option("qkv_attn", 1)
         fullA.visual.set_option("last_block_row0", 1)
 
+def test_mlp_pair_one_launch_is_bit_identical_inside_encode_image(fullA):
+    """Option mlp_pair (hg_mlp_pair.hip: c_fc -> QuickGELU -> c_proj of a block as ONE persistent launch, the c_fc tiles publishing
+    per-row-panel ready counters their c_proj tiles wait for): the same tiles, K loops and epilogues in another order and on other
+    workgroups, so encode_image gives the SAME bits as the two launches - at batch 256, 171 (ragged last panels) and 40 (fewer
+    c_proj tiles than two rounds), with several chunk sizes of the c_fc tile order and with 30 or 24 of an XCD's 32 workgroups running
+    c_fc tiles (the others really wait for their first panels), every row of the last block or the class rows only; repeated launches
+    agree (a race would show up as a difference); the reference's golden crops ride inside the batch."""
+    d = dev()
+    gen = torch.Generator(device=d).manual_seed(77)
+    crops = torch.randn(256, 3, 224, 224, device=d, generator=gen)
+    crops[60:64] = torch.from_numpy(synth.crops(4, 224, seed=1234)).to(d)
+    ref = np.load(f"{G}/g2_vitb16_image.npz")["encode_image"]
+    try:
+        for row0 in (0, 1):
+            fullA.visual.set_option("last_block_row0", row0)
+            for n in (256, 171, 40):
+                fullA.visual.set_option("mlp_pair", 0)
+                want = fullA.encode_image(crops[:n])
+                fullA.visual.set_option("mlp_pair", 1)
+                for chunk, slots in ((8, 32), (8, 30), (3, 24), (25, 30)):
+                    fullA.visual.set_option("mlp_pair_chunk", chunk)
+                    fullA.visual.set_option("mlp_pair_fc_slots", slots)
+                    for rep in range(3 if n == 256 else 1):
+                        got = fullA.encode_image(crops[:n])
+                        assert torch.equal(got, want), (row0, n, chunk, slots, rep, float((got - want).abs().max()))
+        got = fullA.encode_image(crops)[60:64].float().cpu().numpy()
+        assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-3
+    finally:
+        fullA.visual.set_option("mlp_pair", 0)
+        fullA.visual.set_option("mlp_pair_chunk", 8)
+        fullA.visual.set_option("mlp_pair_fc_slots", 30)
+        fullA.visual.set_option("last_block_row0", 1)
+
+
 def test_config4_vae_100k_rows_equals_chunks():
     """BASELINE config 4: 100 000 rows through Encoder -> reparameterise -> Generator in one call == separate calls on the row
     ranges, ragged ranges included - on the GEMM path (option vae_fused = 0: crosses the 32 768-row chunk boundary three times) and on
