@@ -53,7 +53,8 @@ KIND_NAMES = {0: "gemm bias->f16", 1: "gemm bias+QuickGELU->f16", 2: "gemm bias+
               10: "gemm_ring2<residual + x16 + row stats>", 11: "gemm adapter down_proj", 12: "gemm_duo<adapter up_proj>",
               13: "gemm_ring<VAE mean|log_var + reparameterise>", 14: "gemm_duo<adapter up_proj, fp16 copy only>",
               100: "attention_kernel", 101: "qkv_attn_kernel<in_proj + attention, q k v in LDS>",
-              102: "vae_fused_kernel<Encoder/Generator as one kernel: M rows, N passes, K hidden>"}
+              102: "vae_fused_kernel<Encoder/Generator as one kernel: M rows, N passes, K hidden>",
+              103: "mlp_pair_kernel<c_fc + QuickGELU -> c_proj + residual as one launch: M rows, N hidden, K width>"}
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -280,6 +281,7 @@ def config3(model, dev, with_cpu: bool):
     model.truncate_text = False
     out["full_77_tokens"]["rel_l2_vs_reference_fixture"] = rel(model.encode_text(ids_d))
     out["text_ln_fold_settings"] = {}
+    prev_fold = model.get_option("text_ln_fold")      # (restored below: the caller's setting, HG_TEXT_LN_FOLD or the default)
     try:
         for mode, what in ((0, "separate LayerNorm kernels"), (2, "LayerNorm weight folded into the GEMM weights")):
             model.set_option("text_ln_fold", mode)
@@ -288,7 +290,7 @@ def config3(model, dev, with_cpu: bool):
                                                        "frac_nominal": round(T * text_flops(77) / ms / 1e9 / MFMA_PEAK_TFLOPS, 4),
                                                        "rel_l2_vs_reference_fixture": rel(model.encode_text(ids_d))}
     finally:
-        model.set_option("text_ln_fold", 1)
+        model.set_option("text_ln_fold", prev_fold)
     model.truncate_text = True
     if with_cpu:
         from hoigen_amd import synth
@@ -335,6 +337,7 @@ def generation(model, dev):
     executed = prompts.shape[0] * text_flops(Lt, last_block_one_row=True)
     nominal = prompts.shape[0] * text_flops(77)
     # the same loop with the LayerNorm weight folded into the GEMM weights (option text_ln_fold = 2: faster, spends parity margin, see config3)
+    prev_fold = model.get_option("text_ln_fold")
     model.set_option("text_ln_fold", 2)
     try:
         sampler.sample(iterations=bi, generator=gen, batch_iters=bi)
@@ -346,7 +349,7 @@ def generation(model, dev):
         ms_text2 = timed(lambda: sampler.text_encoder(prompts, toks), 5)
         assert bool(torch.isfinite(feat2).all())
     finally:
-        model.set_option("text_ln_fold", 1)
+        model.set_option("text_ln_fold", prev_fold)
     fold = {"option": "text_ln_fold = 2 (not the default)", "ms_per_iteration": round(dt2 / iters * 1e3, 4),
             "features_per_s": round(feat2.shape[0] / dt2, 0), "text_tower_ms": round(ms_text2, 4),
             "text_tower_frac_executed": round(executed / ms_text2 / 1e9 / MFMA_PEAK_TFLOPS, 4)}
@@ -379,12 +382,13 @@ def config4(dev, with_cpu: bool):
     ms_gen = timed(lambda: G(z), 10)
     # the three dispatches of option vae_fused (default 1: Encoder on the GEMM path, Generator of the whole rounds of items as ONE kernel)
     modes = {}
+    prev_vf = vae.get_option("vae_fused", dev)
     try:
         for m_, nm in ((0, "gemm_path"), (2, "one_kernel_every_row")):
             vae.set_option("vae_fused", m_, dev)
             modes[nm] = {"ms": round(timed(lambda: V(x, eps), 10), 4), "generator_only_ms": round(timed(lambda: G(z), 10), 4)}
     finally:
-        vae.set_option("vae_fused", 1, dev)
+        vae.set_option("vae_fused", prev_vf if prev_vf is not None else 1, dev)
     _, recs = _lib.profile(V._slot.get(dev)[1], _lib.HG_PROF_ALL, 64, lambda: V(x, eps))
     out = {"workload": f"CoOp-VAE Encoder->reparameterise->Generator, {R} rows x 512 (BASELINE.json configs[3]); "
                        "inputs and the four outputs (mean, log_var, z, bias) fp32 in HBM",
@@ -423,6 +427,9 @@ def kernel_row(kind, M, N, K):
         rows, D = M * N, K * 64
         return (f"in_proj + attention fused (L={N}, {K} heads)", 2.0 * rows * 3 * D * D + 4.0 * M * K * N * N * 64,
                 rows * D * 2 + 3 * D * D * 2 + rows * D * 2)
+    if kind == 103:                       # the MLP as one launch: x16 in, both weights once, fc written and read once, the stream in and out
+        return (f"c_fc + QuickGELU -> c_proj + residual, one launch (hidden {N}, width {K})", 2 * 2.0 * M * N * K,
+                M * K * 2 + 2 * N * K * 2 + 2 * M * N * 2 + M * K * RLN_STREAM_BYTES)
     fl = 2.0 * M * N * K
     w = N * K * 2
     if kind in (0, 8):
@@ -528,6 +535,7 @@ def run(args):
         per_step = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
         return dt, per_step, recs, out
 
+    prev_row0 = model.visual.get_option("last_block_row0")
     model.visual.set_option("last_block_row0", 0)       # headline: every row of every block (hg_set_option on this context)
     for _ in range(args.warmup):
         step()
@@ -561,7 +569,7 @@ def run(args):
     if args.no_class_rows:
         dt2, rel = dt, 0.0
     else:
-        model.visual.set_option("last_block_row0", 1)
+        model.visual.set_option("last_block_row0", prev_row0 if prev_row0 is not None else 1)
         for _ in range(args.warmup):
             step()
         dt2, per_step2, _, out2 = timed_region()

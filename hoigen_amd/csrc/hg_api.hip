@@ -162,14 +162,18 @@ struct hg_ctx {
                                  // where a call leaves a remainder (600 prompts x 77 tokens: 5.47 -> 5.66 ms)
     int opt_vae_fused = 1;       // CoOp-VAE Encoder -> reparameterise -> Generator as ONE kernel (hg_vae_fused.hip) for the rows that fill
                                  // whole rounds of 128-row items over the CUs (the rest: the GEMM path); 2: every row; 0: GEMM path only
-    int opt_mlp_pair = 0;        // c_fc -> QuickGELU -> c_proj of a LayerNorm-folded block as ONE persistent launch with per-row-panel ready
+    int opt_mlp_pair = 1;        // c_fc -> QuickGELU -> c_proj of a LayerNorm-folded block as ONE persistent launch with per-row-panel ready
                                  // counters between its tiles (hg_mlp_pair.hip; vision tower, variant A); bit-identical to the two launches
-    int opt_mlp_pair_chunk = 8;  // ... 256-row panels of an XCD per chunk
-    int opt_mlp_pair_fc_slots = 30;  // ... workgroups per XCD that run c_fc tiles (the rest start with c_proj)
+    int opt_mlp_pair_chunk = 32; // ... 256-row panels of an XCD per chunk
+    int opt_mlp_pair_fc_slots = 32;  // ... workgroups per XCD that run c_fc tiles (the rest start with c_proj)
     int n_cu = 256;
     // sticky device->host flag (host-mapped): a hand-off wait inside the MLP pair kernel gave up (a workgroup of its grid never became
     // resident); the call in flight returned garbage, the next tower call reports HG_ERR_HIP
     int32_t* pair_err = nullptr;
+    // sticky device->host flag (host-mapped): inside a tower with folded LayerNorms a row reached further from its centre than the centred
+    // fp16 copy / the hi half of the stream can hold (|x - row centre| > 65504, bounded through the row statistics: finalize_stats).
+    // Reported as HG_ERR_INVALID by the next tower call.
+    int32_t* range_flag = nullptr;
     // sticky device->host flag (host-mapped): set by clamp_eot when a caller-supplied text truncation was shorter than
     // max(EOT)+1 (a stale host memo); reported as HG_ERR_INVALID by the next text call
     int32_t* eot_flag = nullptr;
@@ -313,6 +317,21 @@ int as_f32_T(hg_ctx* c, std::vector<void*>& owned, const hg_tensor& t, int rows,
     return HG_OK;
 }
 
+// The MLP of a width-512 block as one kernel (option mlp_fused, hg_vae_fused.hip mode 3) reads its two weights as a packed fragment
+// stream: 4.3 MB per block, 52 MB for the text tower - packed when the option is on at load time or is switched on later, not for
+// every tower (the option defaults to 0: measured a tie).
+int pack_mlp_blocks(hg_ctx* c, std::vector<void*>& owned, std::vector<BlockW>& blocks, int D) {
+    if (!vae_fused_ok(D, 0, 4 * D)) return HG_OK;
+    for (BlockW& b : blocks) {
+        if (b.wp_mlp) continue;
+        int rc = 0;
+        keep_first(rc, dev_alloc(c, owned, vae_fused_pass_bytes(4 * D), (void**)&b.wp_mlp));
+        if (rc) return rc < 0 ? rc : HG_ERR_OOM;
+        HG_HIP(launch_pack_vae(nullptr, nullptr, 0, b.w_fc, b.w_proj, 4 * D, b.wp_mlp, 0));
+    }
+    return HG_OK;
+}
+
 int load_blocks(hg_ctx* c, std::vector<void*>& owned, const hg_block_weights* src, int layers, int D,
                 std::vector<BlockW>& dst, bool fold_ln) {
     if (!src) return fail(c, HG_ERR_INVALID, "blocks == NULL");
@@ -334,11 +353,6 @@ int load_blocks(hg_ctx* c, std::vector<void*>& owned, const hg_block_weights* sr
         keep_first(rc, as_f32(c, owned, s.ln_2_weight, D, &b.ln2_w, "ln_2.weight"));
         keep_first(rc, as_f32(c, owned, s.ln_2_bias, D, &b.ln2_b, "ln_2.bias"));
         if (rc) return rc < 0 ? rc : HG_ERR_INVALID;
-        if (vae_fused_ok(D, 0, 4 * D)) {      // (D = 512: the MLP of the block as one kernel, its hidden layer on chip)
-            keep_first(rc, dev_alloc(c, owned, vae_fused_pass_bytes(4 * D), (void**)&b.wp_mlp));
-            if (rc) return rc < 0 ? rc : HG_ERR_OOM;
-            HG_HIP(launch_pack_vae(nullptr, nullptr, 0, b.w_fc, b.w_proj, 4 * D, b.wp_mlp, 0));
-        }
         if (!fold_ln) continue;
         keep_first(rc, dev_alloc(c, owned, (size_t)3 * D * D * 2, (void**)&b.wf_qkv));
         keep_first(rc, dev_alloc(c, owned, (size_t)3 * D * 4, (void**)&b.cs_qkv));
@@ -358,6 +372,10 @@ int load_blocks(hg_ctx* c, std::vector<void*>& owned, const hg_block_weights* sr
             HG_HIP(launch_pack_qkv(b.wf_qkv, b.bf_qkv, b.cs_qkv, b.wp_qkv, b.bcs_qkv, D, D / 64, 0));
         }
 
+    }
+    if (c->opt_mlp_fused) {
+        int rc = pack_mlp_blocks(c, owned, dst, D);
+        if (rc) return rc;
     }
     return HG_OK;
 }
@@ -648,6 +666,13 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
                                    "became resident): that call's outputs are invalid; set option mlp_pair = 0 if this device cannot "
                                    "hold one workgroup per compute unit");
     }
+    if (c->range_flag && *(volatile int32_t*)c->range_flag) {
+        *(volatile int32_t*)c->range_flag = 0;
+        return fail(c, HG_ERR_INVALID, "in a previous call activations left the fp16 range inside a tower: a row reached more than 65504 from its "
+                                       "centre, which the centred fp16 copy the LayerNorm-folded GEMMs read cannot hold (with option stream_hilo "
+                                       "the residual stream itself is held in it) - that call's embeddings of those rows are invalid.  Option "
+                                       "ln_fuse = 0 selects the separate-LayerNorm path");
+    }
     float* x = (float*)c->x.p;
     half_t* h = (half_t*)c->h.p;
     half_t* qkv = (half_t*)c->qkv.p;
@@ -741,7 +766,9 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
     const int n_rln = fuse ? (row0_plan ? 2 * ((int)blocks.size() - 1) : 2 * (int)blocks.size() - 1) : 0;
     bool all_k2 = adapters && !kmode.empty();
     for (int k : kmode) all_k2 = all_k2 && k == 2;
-    bool hilo = fuse && (!adapters || all_k2) && c->opt_stream_hilo && n_rln >= 2;
+    // (a per-block trace of variant C reads the stream's hi half with row stride D: variant C's lives in [x16 | e] with stride D + 64 - no
+    // entry point asks for that trace today; should one, it gets the fp32 stream)
+    bool hilo = fuse && (!adapters || all_k2) && c->opt_stream_hilo && n_rln >= 2 && !(trace && adapters);
     if (hilo) {
         GemmArgs r{};
         r.M = M; r.N = D; r.ldc = D; r.K = adapters ? D + 64 : D; r.lda = r.K;
@@ -892,7 +919,7 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
             if (!kcat || hilo_c) rln_args(g);
             gs_args(g, b.ln2_w);
             HG_HIP(gemm(c, EPI_RESID_LN_F32, g, s));
-            HG_HIP(launch_finalize_stats(stats, mr, mu, M, sld, 64, s, muc));
+            HG_HIP(launch_finalize_stats(stats, mr, mu, M, sld, 64, s, muc, false, c->range_flag));
         } else {
             HG_HIP(gemm(c, EPI_BIAS_RESID_F32, g, s));
         }
@@ -936,10 +963,7 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
                 HG_HIP(gemm(c, EPI_BIAS_QGELU_F16, g, s));
             }
         }
-        if (mlp_done >= M) {
-            if (trace) HG_HIP(launch_copy_rows(x, trace + (size_t)(i + 1) * trace_stride, n_seq, L, D, s));
-            continue;
-        }
+        if (mlp_done >= M) continue;      // (only without a trace, on the separate-LayerNorm path: the stream is the fp32 x)
         g = GemmArgs{};
         g.A = fc; g.lda = 4 * D; g.W = b.w_proj; g.bias = b.b_proj; g.out = x + (size_t)mlp_done * D; g.ldc = D; g.M = M - mlp_done; g.N = D;
         g.K = 4 * D;
@@ -952,7 +976,7 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
                 gs_args(g, blocks[i + 1].ln1_w);
             }
             if (!paired) HG_HIP(gemm(c, EPI_RESID_LN_F32, g, s));
-            HG_HIP(launch_finalize_stats(stats, mr, mu, M, sld, 64, s, muc));
+            HG_HIP(launch_finalize_stats(stats, mr, mu, M, sld, 64, s, muc, false, c->range_flag));
         } else {
             HG_HIP(gemm(c, EPI_BIAS_RESID_F32, g, s));
         }
@@ -1081,6 +1105,8 @@ hg_ctx* hg_create(int device) {
         else (void)hipMemset(c->eot_flag_dev, 0, 64);
         if (hipHostMalloc((void**)&c->pair_err, 64, hipHostMallocMapped) == hipSuccess && c->pair_err) *c->pair_err = 0;
         else c->pair_err = nullptr;
+        if (hipHostMalloc((void**)&c->range_flag, 64, hipHostMallocMapped) == hipSuccess && c->range_flag) *c->range_flag = 0;
+        else c->range_flag = nullptr;
     }
     struct { const char* env; const char* key; } init[] = {{"HG_CHUNK_ROWS", "chunk_rows"}, {"HG_LAST_BLOCK_ROW0", "last_block_row0"},
                                                            {"HG_LN_FUSE", "ln_fuse"}, {"HG_ADAPTER_FUSE", "adapter_fuse"},
@@ -1128,6 +1154,11 @@ int hg_set_option(hg_ctx* c, const char* key, int value) {
     } else if (k == "mlp_fused") {
         if (value < 0 || value > 2) return fail(c, HG_ERR_INVALID, "mlp_fused must be 0, 1 or 2 (got %d)", value);
         c->opt_mlp_fused = value;
+        if (value && c->text.loaded) {      // the packed operand of that kernel is made on demand
+            HG_ON_DEVICE(c);
+            int rc = pack_mlp_blocks(c, c->text.owned, c->text.blocks, c->text.D);
+            if (rc) return rc;
+        }
     } else if (k == "mlp_pair") {
         if (value < 0 || value > 1) return fail(c, HG_ERR_INVALID, "mlp_pair must be 0 or 1 (got %d)", value);
         c->opt_mlp_pair = value;
@@ -1184,6 +1215,7 @@ void hg_destroy(hg_ctx* c) {
     if (c->eot_flag) (void)hipHostFree(c->eot_flag);
     if (c->eot_flag_dev) (void)hipFree(c->eot_flag_dev);
     if (c->pair_err) (void)hipHostFree(c->pair_err);
+    if (c->range_flag) (void)hipHostFree(c->range_flag);
     delete c;
 }
 
@@ -1935,8 +1967,9 @@ static int text_chunk_prompts(const hg_ctx* c, int n_prompts, int Leff) {
 static int text_tail(hg_ctx* c, int Tc, int Leff, const int32_t* eot, float* out, hipStream_t s) {
     Text& t = c->text;
     const int D = t.D, E = t.E;
-    // the text tower keeps the separate LayerNorm by default: folding (option text_ln_fold) moves its parity error from 6.5e-4 to
-    // 7.6e-4 (worst prompt 9.6e-4) of the 1e-3 budget; since the hi / lo stream it does buy time (600 x 77 tokens: 5.2 -> 4.6 ms)
+    // option text_ln_fold: 1 (default) folds the LayerNorms with gamma riding in the ACTIVATION copy (6.2e-4 against the reference's
+    // fixture, closer than the separate kernels' 6.5e-4, 5.35 -> 5.15 ms for 600 x 77 tokens); 2 folds gamma into the weights (4.8 ms,
+    // 7.6e-4, worst prompt 9.6e-4 of the 1e-3 budget); 0 runs the separate kernels
     const float* rows = nullptr;      // dense EOT rows when the last block ran on them only
     int rc = run_blocks(c, t.blocks, Tc, Leff, D, t.heads, true, s, nullptr, 0, nullptr, c->opt_text_ln_fold != 0, &rows, eot, nullptr,
                         nullptr, nullptr, nullptr, c->opt_text_ln_fold == 1);

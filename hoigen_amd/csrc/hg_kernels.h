@@ -242,8 +242,9 @@ hipError_t launch_layernorm_rowstats(float* x, const float* w, const float* b, h
 // residual GEMM subtracts from its fp16 copy)
 // muc (optional) receives the centre the CURRENT fp16 copy was written with (mu before this call)
 // centred: the statistics are those of ALREADY CENTRED values (EPI_X16_SCALE_LN): mr = (mean, rstd), mu stays
+// range_flag (optional, host-mapped): set to 1 when a row's reach from its centre mu[m], bounded through the statistics, exceeds fp16's 65 504
 hipError_t launch_finalize_stats(const float* stats, float* mr, float* mu, int M, int nt, int gw, hipStream_t s,
-                                 float* muc = nullptr, bool centred = false);
+                                 float* muc = nullptr, bool centred = false, int* range_flag = nullptr);
 #define HG_PRE_HDR 24   // header words per box in the pre-processing table (layout: hg_preproc.hip)
 // ---- crop pre-processing (hg_preproc.hip): head = per-box headers written by the host, tab receives the weight
 // tables at word offsets tab_off[box]; tmp = uint8 scratch for the horizontal pass; out fp32 [n,3,n_px,n_px]; out_u8 (nullable) uint8

@@ -116,7 +116,9 @@ struct MlpProjSched {
     const unsigned* ready;
     int* err;
     __device__ __forceinline__ MlpProjSched(const MlpGeom& g, int M, int N, int n_fc, const unsigned* ready_, int* err_) {
-        x = g.xcd; cu = g.cu; cpx = g.cpx; ch = g.ch; wave = g.wave; ready = ready_; err = err_;
+        // (the list is dealt from the LAST slot down: the c_fc list's remainder goes to the first slots, this one's to the last ones - a slot
+        // owns 10 + 4, 9 + 5 or, two per XCD, 10 + 5 tiles instead of 10 + 5 for twelve: a c_proj tile takes 2.2 c_fc tile times)
+        x = g.xcd; cu = g.cpx - 1 - g.cu; cpx = g.cpx; ch = g.ch; wave = g.wave; ready = ready_; err = err_;
         tn = N / 256;
         const int pf = (M + 255) / 256, pq = (M + 127) / 128;
         const int npx = pf > x ? (pf - x + MLP_NX - 1) / MLP_NX : 0;
@@ -184,6 +186,7 @@ struct MlpPairArgs {
     int ch;               // 256-row panels of an XCD per chunk
     int fc_slots;         // slots per XCD that run c_fc tiles (the others start with c_proj, i.e. wait)
     int census_off;       // byte offset in dynamic LDS of the word through which a workgroup's waves learn their slot
+    unsigned long long* dbg;   // timing experiments (-DHG_PAIR_EXP builds, HG_PAIR_DBG): s_memtime stamps per workgroup
     int only;             // timing experiments (-DHG_PAIR_EXP builds, HG_PAIR_ONLY): 1 = the c_fc tiles alone, 2 = the c_proj tiles alone
                           // (waiting for nothing); wrong results
 };
@@ -212,6 +215,9 @@ __global__ __launch_bounds__(512, 2) void mlp_pair_kernel(const MlpPairArgs P) {
     __syncthreads();
     geo.cu = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(smem + P.census_off));
     if (geo.cu >= geo.cpx) return;      // more workgroups on this XCD than it has slots: the others own all of its work
+#ifdef HG_PAIR_EXP
+    unsigned long long t_stamp[4] = {__builtin_amdgcn_s_memtime(), 0, 0, 0};
+#endif
     {
         MlpFcSched sf(geo, P.fc.M, P.fc.N, P.ready + MLP_CENSUS);
         sf.e0 = 0; sf.n = sf.total;
@@ -224,6 +230,10 @@ __global__ __launch_bounds__(512, 2) void mlp_pair_kernel(const MlpPairArgs P) {
             a.lda = P.fc.lda; a.ldc = P.fc.ldc; a.M = P.fc.M; a.N = P.fc.N; a.K = P.fc.K;
             gemm_ring_body<4, EPI_LN_BIAS_QGELU_F16, true>(a, P.fc.a_bytes, 3000 << 8, sf);
         }
+#ifdef HG_PAIR_EXP
+        t_stamp[1] = __builtin_amdgcn_s_memtime();
+        t_stamp[3] = (unsigned long long)sf.n;
+#endif
     }
     {
         MlpProjSched sp(geo, P.proj.M, P.proj.N, P.proj.K, P.ready + MLP_CENSUS, P.err);
@@ -242,6 +252,14 @@ __global__ __launch_bounds__(512, 2) void mlp_pair_kernel(const MlpPairArgs P) {
             barrier_raw();      // every wave has left the c_fc body (its LDS image is dead)
             gemm_ring2_body<EPI_RESID_LN_F32, HL, false>(a, a.N / 256, P.proj.a_bytes, 0, sp);
         }
+#ifdef HG_PAIR_EXP
+        t_stamp[2] = __builtin_amdgcn_s_memtime();
+        if (P.dbg && threadIdx.x == 0) {
+            unsigned long long* d = P.dbg + (size_t)blockIdx.x * 8;
+            d[0] = t_stamp[0]; d[1] = t_stamp[1]; d[2] = t_stamp[2]; d[3] = t_stamp[3]; d[4] = (unsigned long long)sp.n;
+            d[5] = (unsigned long long)(geo.xcd * 256 + geo.cu);
+        }
+#endif
     }
 #endif
 }
@@ -300,6 +318,36 @@ hipError_t launch_mlp_pair(const GemmArgs& fc, const GemmArgs& proj_in, unsigned
     const int lds = a.census_off + 16;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const int grid = n_cu;
+#ifdef HG_PAIR_EXP
+    static int dbg_left = []() { const char* e = getenv("HG_PAIR_DBG"); return e ? atoi(e) : 0; }();
+    if (dbg_left > 0 && proj.hl == 2) {
+        --dbg_left;
+        unsigned long long* d = nullptr;
+        if (hipMalloc(&d, (size_t)grid * 64) != hipSuccess) return hipErrorOutOfMemory;
+        hipMemsetAsync(d, 0, (size_t)grid * 64, s);
+        a.dbg = d;
+        hipError_t e = launch_pair_t<2>(a, grid, lds, s);
+        hipStreamSynchronize(s);
+        unsigned long long* h = (unsigned long long*)malloc((size_t)grid * 64);
+        hipMemcpy(h, d, (size_t)grid * 64, hipMemcpyDeviceToHost);
+        // s_memtime is not synchronised across CUs: only differences inside a workgroup mean anything.  Group by (c_fc tiles, c_proj tiles).
+        for (int nf = 0; nf <= 12; ++nf)
+            for (int np = 0; np <= 8; ++np) {
+                double f = 0, q = 0, fmin = 1e30, fmax = 0, qmin = 1e30, qmax = 0; int n = 0;
+                for (int b = 0; b < grid; ++b) {
+                    if (!h[b * 8] || (int)h[b * 8 + 3] != nf || (int)h[b * 8 + 4] != np) continue;
+                    const double d1 = (double)(h[b * 8 + 1] - h[b * 8]), d2 = (double)(h[b * 8 + 2] - h[b * 8 + 1]);
+                    f += d1; q += d2; ++n;
+                    fmin = d1 < fmin ? d1 : fmin; fmax = d1 > fmax ? d1 : fmax; qmin = d2 < qmin ? d2 : qmin; qmax = d2 > qmax ? d2 : qmax;
+                }
+                if (n) fprintf(stderr, "[pair-dbg] %3d workgroups with %2d c_fc + %d c_proj tiles: c_fc phase mean %.0f (min %.0f max %.0f) = %.0f per tile | c_proj phase mean %.0f (min %.0f max %.0f) = %.0f per tile [s_memtime ticks]\n",
+                               n, nf, np, f / n, fmin, fmax, nf ? f / n / nf : 0.0, q / n, qmin, qmax, np ? q / n / np : 0.0);
+            }
+        free(h);
+        hipFree(d);
+        return e;
+    }
+#endif
     switch (proj.hl) {
         case 0: return launch_pair_t<0>(a, grid, lds, s);
         case 2: return launch_pair_t<2>(a, grid, lds, s);

@@ -486,7 +486,32 @@ hipError_t launch_pack_vae(const half_t* e_w0, const half_t* e_wml, int eh, cons
     return hipGetLastError();
 }
 
+static hipError_t launch_vae_fused_slice(const VaeFusedArgs& a, hipStream_t s);
+
+// The kernel addresses the [R, 512] fp32 tensors with 32-bit byte offsets: at most 2^20 rows per launch.  Longer calls run as slices of
+// 2^20 rows (whole work items, whole rounds of items over 256 CUs); rows are independent, so the slicing does not change a bit.
 hipError_t launch_vae_fused(const VaeFusedArgs& a, hipStream_t s) {
+    constexpr int SLICE = 1 << 20;
+    if (a.R <= SLICE) return launch_vae_fused_slice(a, s);
+    for (int r0 = 0; r0 < a.R; r0 += SLICE) {
+        VaeFusedArgs b = a;
+        const size_t o = (size_t)r0 * 512;
+        b.R = a.R - r0 < SLICE ? a.R - r0 : SLICE;
+        if (a.x) b.x = a.x + o;
+        if (a.x16) b.x16 = a.x16 + o;
+        if (a.eps) b.eps = a.eps + o;
+        if (a.mean) b.mean = a.mean + o;
+        if (a.logvar) b.logvar = a.logvar + o;
+        if (a.z) b.z = a.z + o;
+        if (a.bias) b.bias = a.bias + o;
+        if (a.zpark) b.zpark = a.zpark + vae_fused_park_bytes(r0) / sizeof(half_t);
+        hipError_t e = launch_vae_fused_slice(b, s);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+static hipError_t launch_vae_fused_slice(const VaeFusedArgs& a, hipStream_t s) {
     if (a.R <= 0 || (!a.x && !(a.mode >= 2 && a.x16)) || !a.wp || a.mode < 0 || a.mode > 3) return hipErrorInvalidValue;
     if (a.mode < 2 && (!a.eps || !a.b0e || !a.bml || !a.zpark)) return hipErrorInvalidValue;
     if (a.mode != 1 && (!a.b0g || !a.b2g || !a.bias)) return hipErrorInvalidValue;

@@ -113,6 +113,7 @@ class FeatureSampler:
         feats: "Dict[str, List[torch.Tensor]]" = {k: [] for k in self.branches}
         saved = {k: b.target for k, b in self.branches.items()}
         done = 0
+        prev_fold = self.clip.get_option("text_ln_fold") if self.text_ln_fold is not None else None
         if self.text_ln_fold is not None:
             self.clip.set_option("text_ln_fold", int(self.text_ln_fold))
         try:
@@ -130,7 +131,7 @@ class FeatureSampler:
             for k, b in self.branches.items():
                 b.target = saved[k]
             if self.text_ln_fold is not None:
-                self.clip.set_option("text_ln_fold", 1)      # (the library default)
+                self.clip.set_option("text_ln_fold", prev_fold)      # (what was in force before: the caller's choice, not a constant)
         gen_feature = torch.cat([torch.cat(feats[k], dim=0) for k in self.branches], dim=0)
         gen_target = torch.cat([b.target.to(dev).repeat(iterations) for b in self.branches.values()], dim=0)
         return gen_feature, gen_target

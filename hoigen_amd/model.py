@@ -99,9 +99,23 @@ class _Ctx:
     def set_option(self, key: str, value: int) -> None:
         """Behaviour option of this model's native context (include/hoigen_amd.h: hg_set_option), e.g. ``last_block_row0``,
         ``ln_fuse``, ``adapter_fuse``, ``adapter_fold``, ``chunk_rows``.  Survives a move to another device."""
+        if value is None:      # (what get_option returned before a context existed: back to "nothing applied")
+            if self.handle is None:
+                self.options.pop(key, None)
+            return
         if self.handle is not None:
             self.check(_lib.lib().hg_set_option(self.handle, key.encode(), int(value)), f"hg_set_option({key})")
         self.options[key] = int(value)
+
+    def get_option(self, key: str):
+        """Current value of a behaviour option: the native context's (hg_get_option) once it exists, else the value recorded for it,
+        else None (= the library default, nothing applied yet).  ``set_option(key, get_option(key))`` restores what was in force;
+        None is accepted by ``set_option`` for that purpose."""
+        if self.handle is not None:
+            v = _lib.C.c_int32()
+            self.check(_lib.lib().hg_get_option(self.handle, key.encode(), _lib.C.byref(v)), f"hg_get_option({key})")
+            return int(v.value)
+        return self.options.get(key)
 
     def check(self, rc: int, what: str) -> None:
         if rc != 0:
@@ -395,6 +409,14 @@ class VisionTransformer(nn.Module):
         """Behaviour option of this tower's native context (include/hoigen_amd.h: hg_set_option)."""
         self._ctx.set_option(key, value)
 
+    def get_option(self, key: str):
+        """The option's current value.  On a HIP device the native context is created if need be and asked (hg_get_option); a model still
+        on the CPU answers with the value recorded for it or None (= library default: set_option(key, None) is a no-op then)."""
+        dev = self.positional_embedding.device
+        if dev.type == "cuda":
+            self._ctx.get(dev)
+        return self._ctx.get_option(key)
+
     @torch.no_grad()
     def forward_trace(self, x: torch.Tensor):
         """Test hook: (embedding [B,E], CLS rows after ln_pre and every block [layers+1,B,D])."""
@@ -531,6 +553,13 @@ class CLIP(nn.Module):
         """Behaviour option (hg_set_option) for both towers of this model."""
         self.visual.set_option(key, value)
         self._ctx.set_option(key, value)
+
+    def get_option(self, key: str):
+        """The option's current value in the text tower's context (see VisionTransformer.get_option)."""
+        dev = self.positional_embedding.device
+        if dev.type == "cuda":
+            self._ctx.get(dev)
+        return self._ctx.get_option(key)
 
     # -- public API -----------------------------------------------------------------------------------
     def encode_image(self, image: torch.Tensor):

@@ -95,7 +95,19 @@ def set_option(key: str, value: int, device=None) -> None:
         pool = _Slot._pools.get(idx)
         if pool is None:
             pool = _Slot._pools[idx] = {"ctx": _Ctx(), "vae": list(range(_lib.HG_MAX_SLOTS)), "mlp": list(range(_lib.HG_MAX_SLOTS))}
-        pool["ctx"].set_option(key, value)
+        pool["ctx"].set_option(key, value)      # (None = what get_option returned before a context existed: nothing to undo)
+
+
+def get_option(key: str, device=None):
+    """Current value of a behaviour option in the VAE-family context of ``device`` (None: library default, no context yet)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    with _Slot._lock:
+        pool = _Slot._pools.get(idx)
+        if pool is None:
+            pool = _Slot._pools[idx] = {"ctx": _Ctx(), "vae": list(range(_lib.HG_MAX_SLOTS)), "mlp": list(range(_lib.HG_MAX_SLOTS))}
+        pool["ctx"].get(dev)      # (the native context answers: created here if this is the first use of the device)
+        return pool["ctx"].get_option(key)
 
 
 class _Session:

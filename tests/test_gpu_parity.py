@@ -406,6 +406,63 @@ def test_batch256_invariance_and_determinism(fullA):
     assert torch.equal(out300[:256], out) and torch.equal(out300[256:], out[:44])
 
 
+def test_batch256_every_row_vs_oracle(fullA):
+    """BASELINE config 2 at full size, every row compared: all 256 crops of a batch through the CPU oracle (oracle/clip_oracle.py, pinned
+    to the reference's fixtures; ~15-30 s on the host cores) against the production path - every row of the last block computed (the
+    headline's work) and the class rows only (the library's default) -, the one-launch MLP on and off.  Tolerance: relative L2 <= 1e-3
+    for the whole matrix and for EVERY row (north_star); the worst row is printed."""
+    from oracle import clip_oracle as co
+    d = dev()
+    gen = torch.Generator().manual_seed(2560)
+    crops = torch.randn(256, 3, 224, 224, generator=gen)
+    sd = co.reference_weight_rounding(synth.clip_state_dict(synth.VIT_B16, 0))
+    with torch.no_grad():
+        want = torch.cat([co.encode_image(sd, crops[i:i + 32]) for i in range(0, 256, 32)]).numpy()
+    x = crops.to(d)
+    try:
+        for row0 in (0, 1):
+            fullA.visual.set_option("last_block_row0", row0)
+            for pair in (1, 0):
+                fullA.visual.set_option("mlp_pair", pair)
+                got = fullA.visual.forward_trace(x)[0]
+                whole, worst = rel_l2(got, want)
+                print(f"\nbatch 256 vs oracle, last_block_row0={row0} mlp_pair={pair}: rel-L2 {whole:.3e}, worst of 256 rows {worst:.3e}")
+                assert whole <= TOL and worst <= TOL, (row0, pair, whole, worst)
+    finally:
+        fullA.visual.set_option("last_block_row0", 1)
+        fullA.visual.set_option("mlp_pair", 1)
+
+
+def test_activation_range_overflow_is_reported():
+    """The LayerNorm-folded towers hold x - (row centre) as fp16 (the GEMM operand copy; with option stream_hilo the stream itself): a
+    row that reaches further than 65 504 from its centre overflows it.  finalize_stats sees every row's statistics, which bound that
+    reach: when the bound leaves the range a sticky flag makes the NEXT tower call fail (HG_ERR_INVALID -> RuntimeError) with an
+    explanation - the overflowing call itself cannot be failed without a synchronisation; its rows come out non-finite.  A crop that
+    comes in non-finite is NOT reported (NaN statistics compare false: the reference returns NaN for it too)."""
+    d = dev()
+    sd = synth.clip_state_dict(synth.VIT_B16, 0)
+    for blk in (3, 4):      # (the weights themselves are fp16: 6e4 per block, 1.2e5 off the row's centre in one channel from block 4 on)
+        key = f"visual.transformer.resblocks.{blk}.mlp.c_proj.bias"
+        sd[key] = sd[key].copy()
+        sd[key][5] = 6.0e4
+    m = build_model(synth.to_torch(sd)).to(d)
+    x = torch.from_numpy(synth.crops(4, 224, seed=77)).to(d).repeat(8, 1, 1, 1)      # 32 crops: M = 6304 >= 512, the folded path
+    out = m.visual.forward_trace(x)[0]
+    torch.cuda.synchronize()
+    assert not torch.isfinite(out).all(), "the stress weights did not leave the fp16 range"
+    with pytest.raises(RuntimeError, match="left the fp16 range inside a tower"):
+        m.encode_image(x)
+    # the report is consumed by the call that raised: a model in range runs on the same device right after
+    # a NaN crop is the caller's business, not a range overflow: no report
+    m2 = build_model(synth.to_torch(synth.clip_state_dict(synth.VIT_B16, 0))).to(d)
+    x2 = x.clone()
+    x2[3, 0, 0, 0] = float("nan")
+    o2 = m2.visual.forward_trace(x2)[0]
+    torch.cuda.synchronize()
+    assert not torch.isfinite(o2[3]).any() and torch.isfinite(o2[:3]).all() and torch.isfinite(o2[4:]).all()
+    m2.encode_image(x)
+
+
 def test_layernorm_folding_matches_separate_layernorm(fullA, g0, monkeypatch):
     """The vision tower folds LayerNorm into its GEMMs for M >= 512; option ln_fuse = 0 selects the separate-LayerNorm
     path.  Both must sit within the parity tolerance of the reference and of each other.  The switch reaches the text tower as well

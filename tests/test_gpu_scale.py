@@ -100,7 +100,7 @@ def test_mlp_pair_one_launch_is_bit_identical_inside_encode_image(fullA):
                 fullA.visual.set_option("mlp_pair", 0)
                 want = fullA.encode_image(crops[:n])
                 fullA.visual.set_option("mlp_pair", 1)
-                for chunk, slots in ((8, 32), (8, 30), (3, 24), (25, 30)):
+                for chunk, slots in ((32, 32), (8, 30), (3, 24), (25, 30)):
                     fullA.visual.set_option("mlp_pair_chunk", chunk)
                     fullA.visual.set_option("mlp_pair_fc_slots", slots)
                     for rep in range(3 if n == 256 else 1):
@@ -109,10 +109,37 @@ def test_mlp_pair_one_launch_is_bit_identical_inside_encode_image(fullA):
         got = fullA.encode_image(crops)[60:64].float().cpu().numpy()
         assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-3
     finally:
-        fullA.visual.set_option("mlp_pair", 0)
-        fullA.visual.set_option("mlp_pair_chunk", 8)
-        fullA.visual.set_option("mlp_pair_fc_slots", 30)
+        fullA.visual.set_option("mlp_pair", 1)
+        fullA.visual.set_option("mlp_pair_chunk", 32)
+        fullA.visual.set_option("mlp_pair_fc_slots", 32)
         fullA.visual.set_option("last_block_row0", 1)
+
+
+def test_generator_above_a_million_rows():
+    """hg_generator / hg_vae_forward on more than 2^20 rows (the one-kernel path addresses its [R, 512] tensors with 32-bit byte
+    offsets, i.e. 2^20 rows per launch - the default dispatch used to hand it 1 081 344 rows of a 1.1 M-row call and fail): the launcher
+    slices at 2^20 rows.  Rows on both sides of the slice boundary equal the same rows of a short call bit for bit (option vae_fused = 2:
+    every row through the one kernel), and the default dispatch agrees with it to fp32 summation order."""
+    d = dev()
+    Gn = vae.Generator().to(d)
+    Gn.load_state_dict(synth.to_torch(synth.generator_state_dict(3)))
+    R = 1_100_000
+    gen = torch.Generator(device=d).manual_seed(11)
+    z = torch.randn(R, 512, device=d, generator=gen)
+    lo, hi = (1 << 20) - 300, (1 << 20) + 300
+    try:
+        vae.set_option("vae_fused", 2, d)
+        whole = Gn(z)
+        assert torch.isfinite(whole[::4099]).all()
+        part = Gn(z[lo:hi].contiguous())
+        assert torch.equal(whole[lo:hi], part)
+        assert torch.equal(whole[:128], Gn(z[:128].contiguous()))
+        vae.set_option("vae_fused", 1, d)
+        dflt = Gn(z)
+        rel = float((dflt[lo:hi].double() - whole[lo:hi].double()).norm() / whole[lo:hi].double().norm())
+        assert rel < 1e-5, rel
+    finally:
+        vae.set_option("vae_fused", 1, d)
 
 
 def test_config4_vae_100k_rows_equals_chunks():
