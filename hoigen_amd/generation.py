@@ -55,12 +55,14 @@ class FeatureSampler:
         return self._lt
 
     @torch.no_grad()
-    def step(self, z: "Dict[str, torch.Tensor]") -> "Dict[str, torch.Tensor]":
+    def step(self, z: "Dict[str, torch.Tensor]", targets: "Optional[Dict[str, torch.Tensor]]" = None) -> "Dict[str, torch.Tensor]":
         """One loop iteration for given latents ``z[name] [n_name, 512]`` -> features per branch.  With a truncating text tower
         (``clip_model.truncate_text``, the default) the prompts are assembled with the tokens it reads only, each branch straight into
-        its slice of the one batch the tower is called with."""
+        its slice of the one batch the tower is called with.  ``targets[name]``: the class of every row of ``z[name]`` (default: the
+        branch's own ``target``; ``sample`` passes the stacked targets of several iterations - the branches are not modified)."""
         names = list(self.branches)
-        sizes = [len(self.branches[k].target) for k in names]
+        tg = {k: (targets[k] if targets is not None else self.branches[k].target) for k in names}
+        sizes = [len(tg[k]) for k in names]
         dev = z[names[0]].device
         lt = self._tokens_run() if getattr(self.clip, "truncate_text", False) else None
         L = lt if lt is not None else 1 + self.branches[names[0]].prompt_learner.n_ctx + self.branches[names[0]].prompt_learner.token_suffix.shape[1]
@@ -68,7 +70,7 @@ class FeatureSampler:
         toks, o = [], 0
         for name, n in zip(names, sizes):
             br = self.branches[name]
-            tgt = br.target.to(dev)
+            tgt = tg[name].to(dev)
             bias = br.generator(z[name])
             br.prompt_learner(bias, tgt, out=prompts[o:o + n], tokens=lt)
             toks.append(br.prompt_learner.tokenized_prompts[tgt])
@@ -111,7 +113,6 @@ class FeatureSampler:
         if batch_iters <= 0:
             batch_iters = self._auto_batch(iterations)      # (0: chosen from the shapes)
         feats: "Dict[str, List[torch.Tensor]]" = {k: [] for k in self.branches}
-        saved = {k: b.target for k, b in self.branches.items()}
         done = 0
         prev_fold = self.clip.get_option("text_ln_fold") if self.text_ln_fold is not None else None
         if self.text_ln_fold is not None:
@@ -119,17 +120,14 @@ class FeatureSampler:
         try:
             while done < iterations:
                 k_it = min(max(1, batch_iters), iterations - done)
-                zs = [{k: torch.randn(len(saved[k]), b.generator.dim, device=dev, generator=generator) for k, b in self.branches.items()}
+                zs = [{k: torch.randn(len(b.target), b.generator.dim, device=dev, generator=generator) for k, b in self.branches.items()}
                       for _ in range(k_it)]
-                for k, b in self.branches.items():
-                    b.target = saved[k].repeat(k_it)
                 z = {k: torch.cat([zi[k] for zi in zs], dim=0) for k in self.branches}
-                for k, v in self.step(z).items():
+                stacked = {k: b.target.repeat(k_it) for k, b in self.branches.items()}      # (passed down: the branches stay as they are)
+                for k, v in self.step(z, stacked).items():
                     feats[k].append(v)
                 done += k_it
         finally:
-            for k, b in self.branches.items():
-                b.target = saved[k]
             if self.text_ln_fold is not None:
                 self.clip.set_option("text_ln_fold", prev_fold)      # (what was in force before: the caller's choice, not a constant)
         gen_feature = torch.cat([torch.cat(feats[k], dim=0) for k in self.branches], dim=0)

@@ -20,7 +20,7 @@ PY
     for c in FETCH_SIZE WRITE_SIZE; do
       rm -rf $R/gpurun_out/pmc_$c; rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-configs --no-class-rows > $R/gpurun_out/pmc_$c.log 2>&1
     done
-    python3 $R/tools/step_traffic.py $name 5 $R/gpurun_out/pmc_FETCH_SIZE $R/gpurun_out/pmc_WRITE_SIZE | grep -v '^{'
+    python3 $R/tools/step_traffic.py $name 7 $R/gpurun_out/pmc_FETCH_SIZE $R/gpurun_out/pmc_WRITE_SIZE | grep -v '^{'
   fi
   if [ "$envs" != "-" ]; then for kv in ${envs//,/ }; do unset ${kv%%=*}; done; fi
 done
