@@ -163,7 +163,8 @@ struct hg_ctx {
     int opt_vae_fused = 1;       // CoOp-VAE Encoder -> reparameterise -> Generator as ONE kernel (hg_vae_fused.hip) for the rows that fill
                                  // whole rounds of 128-row items over the CUs (the rest: the GEMM path); 2: every row; 0: GEMM path only
     int opt_mlp_pair = 1;        // c_fc -> QuickGELU -> c_proj of a LayerNorm-folded block as ONE persistent launch with per-row-panel ready
-                                 // counters between its tiles (hg_mlp_pair.hip; vision tower, variant A); bit-identical to the two launches
+                                 // counters between its tiles (hg_mlp_pair.hip; both towers, variant A); bit-identical to the two launches;
+                                 // 2: finalize_stats of the next LayerNorm in the launch's tail as well
     int opt_mlp_pair_chunk = 32; // ... 256-row panels of an XCD per chunk
     int opt_mlp_pair_fc_slots = 32;  // ... workgroups per XCD that run c_fc tiles (the rest start with c_proj)
     int n_cu = 256;
@@ -810,10 +811,10 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         if (g.hl == 1 || g.hl == 2) { g.out3 = hg; g.ld3 = D; a_ln = hg; }
         else a_ln = h;
     };
-    // c_fc and c_proj of a block as ONE persistent launch (option mlp_pair, hg_mlp_pair.hip): LayerNorm-folded blocks without adapters and
-    // without the activation-side gamma, where c_proj is a LayerNorm-emitting residual GEMM (every block but the tower's last)
+    // c_fc and c_proj of a block as ONE persistent launch (option mlp_pair, hg_mlp_pair.hip): LayerNorm-folded blocks without adapters
+    // where c_proj is a LayerNorm-emitting residual GEMM on the hi / lo (or fp32) stream (every block but the tower's last)
     const int pair_panels = (int)rup(mlp_pair_ready_words(M), 64);      // words per block: the census, then a counter per 256-row panel
-    const bool pair_on = fuse && !adapters && !gs && c->opt_mlp_pair && c->pair_err && blocks.size() > 1;
+    const bool pair_on = fuse && !adapters && c->opt_mlp_pair && c->pair_err && blocks.size() > 1;
     if (pair_on) {
         int rc = ensure(c, c->pair_ready, blocks.size() * (size_t)pair_panels * 4);
         if (rc) return rc;
@@ -927,7 +928,7 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
         g.A = h; g.lda = D; g.out = fc; g.ldc = 4 * D; g.M = M; g.N = 4 * D; g.K = D;
         int mlp_done = 0;      // leading rows whose MLP ran as the one kernel (separate-LayerNorm path, width 512)
         GemmArgs pq{};         // option mlp_pair: the c_proj arguments, built ahead of c_fc (pq_built), and whether the pair kernel took both
-        bool pq_built = false, paired = false;
+        bool pq_built = false, paired = false, pair_fin = false;
         if (fuse) {
             g.W = b.wf_fc; g.bias = b.bf_fc; g.cs = b.cs_fc; g.mr = mr;
             if (hilo_c) { g.A = att; g.lda = D + 64; }
@@ -936,12 +937,18 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
                 pq.A = fc; pq.lda = 4 * D; pq.W = b.w_proj; pq.bias = b.b_proj; pq.out = x; pq.ldc = D; pq.M = M; pq.N = D; pq.K = 4 * D;
                 pq.out2 = h_of(i + 1); pq.ld2 = ldh_of(i + 1); pq.stats = stats; pq.stats_ld = sld; pq.mu = mu;
                 rln_args(pq);
+                gs_args(pq, blocks[i + 1].ln1_w);
                 pq_built = true;
                 if (mlp_pair_ok(g, pq, c->n_cu)) {
                     ProfScope ps(c, s, HG_PROF_MLP_PAIR, M, 4 * D, D);
+                    // (option mlp_pair = 2: the launch's tail also does finalize_stats' work - measured +10 us on the launch for the 5 us
+                    // launch it removes in the vision tower, a tie in the text tower (profiles/r06_mlp_pair.txt item 8); 1: its own launch)
+                    const bool fin = c->opt_mlp_pair == 2;
                     HG_HIP(launch_mlp_pair(g, pq, (unsigned*)c->pair_ready.p + i * (size_t)pair_panels, c->pair_err,
-                                           c->opt_mlp_pair_chunk, c->opt_mlp_pair_fc_slots, c->n_cu, s));
+                                           c->opt_mlp_pair_chunk, c->opt_mlp_pair_fc_slots, c->n_cu, s, fin ? mr : nullptr, mu, muc,
+                                           c->range_flag));
                     paired = true;
+                    pair_fin = fin;
                 }
             }
             if (!paired) HG_HIP(gemm(c, EPI_LN_BIAS_QGELU_F16, g, s));
@@ -976,7 +983,7 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
                 gs_args(g, blocks[i + 1].ln1_w);
             }
             if (!paired) HG_HIP(gemm(c, EPI_RESID_LN_F32, g, s));
-            HG_HIP(launch_finalize_stats(stats, mr, mu, M, sld, 64, s, muc, false, c->range_flag));
+            if (!pair_fin) HG_HIP(launch_finalize_stats(stats, mr, mu, M, sld, 64, s, muc, false, c->range_flag));
         } else {
             HG_HIP(gemm(c, EPI_BIAS_RESID_F32, g, s));
         }
@@ -1160,7 +1167,7 @@ int hg_set_option(hg_ctx* c, const char* key, int value) {
             if (rc) return rc;
         }
     } else if (k == "mlp_pair") {
-        if (value < 0 || value > 1) return fail(c, HG_ERR_INVALID, "mlp_pair must be 0 or 1 (got %d)", value);
+        if (value < 0 || value > 2) return fail(c, HG_ERR_INVALID, "mlp_pair must be 0, 1 or 2 (got %d)", value);
         c->opt_mlp_pair = value;
     } else if (k == "mlp_pair_chunk") {
         if (value < 1 || value > 64) return fail(c, HG_ERR_INVALID, "mlp_pair_chunk must be 1 .. 64 (got %d)", value);

@@ -708,46 +708,7 @@ __global__ void finalize_stats_kernel(const float* __restrict__ stats, float* __
                                       int M, int nt, int gw, float* __restrict__ muc, int centred, int* __restrict__ range_flag) {
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
-    const float* sp = stats + (size_t)m * nt * 2;
-    float s1 = 0.f, m2 = 0.f;
-    const float D = (float)(nt * gw);
-    float mean;
-    const float c = mu[m];
-    float reach = 0.f;      // upper bound of |x - c| over the row: per column group, sqrt(sum of squared deviations) + |group mean - c|
-    if (nt == 12) {      // D = 768: the row's 24 floats as six 16-byte loads (same order of additions as the loop below)
-        f32x4 v[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) v[i] = reinterpret_cast<const f32x4*>(sp)[i];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) { s1 += v[i][0]; s1 += v[i][2]; }
-        mean = s1 / D;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const float d0 = v[i][0] / (float)gw - mean;
-            m2 += v[i][1] + (float)gw * d0 * d0;
-            const float d1 = v[i][2] / (float)gw - mean;
-            m2 += v[i][3] + (float)gw * d1 * d1;
-            reach = fmaxf(reach, fmaxf(sqrtf(v[i][1]) + fabsf(v[i][0] / (float)gw - c), sqrtf(v[i][3]) + fabsf(v[i][2] / (float)gw - c)));
-        }
-    } else {
-        for (int t = 0; t < nt; ++t) s1 += sp[2 * t];
-        mean = s1 / D;
-        for (int t = 0; t < nt; ++t) {
-            const float d = sp[2 * t] / (float)gw - mean;
-            m2 += sp[2 * t + 1] + (float)gw * d * d;
-            reach = fmaxf(reach, sqrtf(sp[2 * t + 1]) + fabsf(sp[2 * t] / (float)gw - c));
-        }
-    }
-    mr[2 * (size_t)m] = centred ? mean : mean - c;   // the fp16 copy of this row was written as x - mu[m]
-    mr[2 * (size_t)m + 1] = 1.0f / sqrtf(m2 / D + 1e-5f);
-    // The copy of this row the folded GEMMs read (and, with the stream held as hi / lo, the stream itself) was just written as
-    // fp16(x - c): an element more than 65 504 from the centre overflows it.  The statistics bound the row's reach from above (no
-    // element is further from c than its group's root sum of squared deviations + the group mean's distance), so a row is reported
-    // when that bound leaves the range - before anything has turned non-finite, and never for a row that came in non-finite (NaN
-    // compares false).  The word is host-mapped and sticky: the NEXT tower call reports it (hg_api.hip).
-    if (range_flag && !centred && reach > 65504.0f) *range_flag = 1;
-    if (muc) muc[m] = c;                          // centre of the current copy (adapter down_proj adds it back)
-    if (!centred) mu[m] = mean;                   // centre for the next residual GEMM's copy
+    finalize_stats_row<false>(stats + (size_t)m * nt * 2, mr, mu, muc, m, nt, gw, centred, range_flag);      // (hg_gemm_dev.h)
 }
 hipError_t launch_finalize_stats(const float* stats, float* mr, float* mu, int M, int nt, int gw, hipStream_t s, float* muc,
                                  bool centred, int* range_flag) {

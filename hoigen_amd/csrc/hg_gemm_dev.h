@@ -97,6 +97,83 @@ __device__ __forceinline__ float sum_rows(float x) {
     return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
 }
 
+// LayerNorm statistics of one row from the partial sums the residual GEMMs emit (finalize_stats_kernel, hg_elem.hip; the tail of the
+// MLP pair kernel, hg_mlp_pair.hip - one function, so that a row's (mean, rstd) do not depend on which of the two ran): stats [nt][2] =
+// per column group of gw columns (sum, sum of squared deviations from the group mean), combined with Chan's formula -> mr = (mean - c, rstd)
+// with c = mu[m] the centre the row's fp16 copy was written with (centred: mr = (mean, rstd), mu stays), then mu[m] = mean, muc[m] = c.
+// SC1: the partial sums were written by other workgroups of this launch (same XCD): read them past this CU's vector L1.
+template <bool SC1>
+__device__ __forceinline__ void finalize_stats_row(const float* sp, float* mr, float* mu, float* muc, int m, int nt, int gw, int centred,
+                                                   int* range_flag) {
+    float s1 = 0.f, m2 = 0.f;
+    const float D = (float)(nt * gw);
+    float mean;
+    const float c = mu[m];
+    float reach = 0.f;      // upper bound of |x - c| over the row: per column group, sqrt(sum of squared deviations) + |group mean - c|
+    auto ld4 = [&](int i) {
+        if constexpr (SC1) {
+            typedef float f32x4g __attribute__((ext_vector_type(4)));
+            f32x4 v;
+            const f32x4g* q = reinterpret_cast<const f32x4g*>(sp) + i;
+            asm volatile("global_load_dwordx4 %0, %1, off sc1\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(q) : "memory");
+            return v;
+        } else {
+            return reinterpret_cast<const f32x4*>(sp)[i];
+        }
+    };
+    if (nt == 12) {      // D = 768: the row's 24 floats as six 16-byte loads (same order of additions as the loop below)
+        f32x4 v[6];
+        if constexpr (SC1) {      // all six in flight, ONE wait (a wait per load costs six L2 round trips: 10 us in the pair kernel's tail)
+            typedef float f32x4g __attribute__((ext_vector_type(4)));
+            const f32x4g* q = reinterpret_cast<const f32x4g*>(sp);
+            asm volatile("global_load_dwordx4 %0, %6, off sc1\n global_load_dwordx4 %1, %6, off offset:16 sc1\n"
+                         "global_load_dwordx4 %2, %6, off offset:32 sc1\n global_load_dwordx4 %3, %6, off offset:48 sc1\n"
+                         "global_load_dwordx4 %4, %6, off offset:64 sc1\n global_load_dwordx4 %5, %6, off offset:80 sc1\n s_waitcnt vmcnt(0)"
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]) : "v"(q) : "memory");
+        } else {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) v[i] = ld4(i);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { s1 += v[i][0]; s1 += v[i][2]; }
+        mean = s1 / D;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const float d0 = v[i][0] / (float)gw - mean;
+            m2 += v[i][1] + (float)gw * d0 * d0;
+            const float d1 = v[i][2] / (float)gw - mean;
+            m2 += v[i][3] + (float)gw * d1 * d1;
+            reach = fmaxf(reach, fmaxf(sqrtf(v[i][1]) + fabsf(v[i][0] / (float)gw - c), sqrtf(v[i][3]) + fabsf(v[i][2] / (float)gw - c)));
+        }
+    } else {
+        for (int t = 0; t < nt; t += 2) {      // (nt = 4 * N / 256 is even)
+            const f32x4 v = ld4(t / 2);
+            s1 += v[0];
+            s1 += v[2];
+        }
+        mean = s1 / D;
+        for (int t = 0; t < nt; t += 2) {
+            const f32x4 v = ld4(t / 2);
+            const float d0 = v[0] / (float)gw - mean;
+            m2 += v[1] + (float)gw * d0 * d0;
+            reach = fmaxf(reach, sqrtf(v[1]) + fabsf(v[0] / (float)gw - c));
+            const float d1 = v[2] / (float)gw - mean;
+            m2 += v[3] + (float)gw * d1 * d1;
+            reach = fmaxf(reach, sqrtf(v[3]) + fabsf(v[2] / (float)gw - c));
+        }
+    }
+    mr[2 * (size_t)m] = centred ? mean : mean - c;   // the fp16 copy of this row was written as x - mu[m]
+    mr[2 * (size_t)m + 1] = 1.0f / sqrtf(m2 / D + 1e-5f);
+    // The copy of this row the folded GEMMs read (and, with the stream held as hi / lo, the stream itself) was just written as
+    // fp16(x - c): an element more than 65 504 from the centre overflows it.  The statistics bound the row's reach from above (no
+    // element is further from c than its group's root sum of squared deviations + the group mean's distance), so a row is reported
+    // when that bound leaves the range - before anything has turned non-finite, and never for a row that came in non-finite (NaN
+    // compares false).  The word is host-mapped and sticky: the NEXT tower call reports it (hg_api.hip).
+    if (range_flag && !centred && reach > 65504.0f) *range_flag = 1;
+    if (muc) muc[m] = c;                          // centre of the current copy (adapter down_proj adds it back)
+    if (!centred) mu[m] = mean;                   // centre for the next residual GEMM's copy
+}
+
 // Tile schedule of the stand-alone persistent kernels (gemm_ring, gemm_ring2).  Tile order (L2 locality): the list is n-group-major
 // (groups of `gsz` column tiles whose W slices fit one XCD's L2 together), m-tile next, column tile inside the group fastest.  XCD x
 // (= blockIdx % 8 under round-robin placement; speed only) owns the contiguous list range [x*T8, (x+1)*T8) and its CUs walk it 'cpx'

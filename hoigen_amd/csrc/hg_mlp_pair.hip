@@ -177,11 +177,24 @@ struct MlpProjArgs {
     const float* muc;
     int lda, ldc, ld2, M, N, K, stats_ld;
     unsigned a_bytes;
+    // GS instances (the text tower: the next LayerNorm's weight rides in the activation copy, GemmArgs::gamma)
+    const float* gamma;
+    half_t* out3;
+    int ld3;
+};
+// the launch's tail: what finalize_stats would do in a launch of its own (read from the kernel-argument segment where it is needed)
+struct MlpFinArgs {
+    float* mr;            // [M][2]; null = the tail is off (the caller launches finalize_stats)
+    float* mu;            // [M]
+    float* muc;           // [M] or null
+    int* range_flag;      // host-mapped, or null
 };
 struct MlpPairArgs {
     MlpFcArgs fc;
     MlpProjArgs proj;
-    unsigned* ready;      // [MLP_CENSUS + ceil(M / 256)] zeroed before the launch: the census words, then the panels' counters
+    MlpFinArgs fin;
+    unsigned* ready;      // [mlp_pair_ready_words(M)] zeroed before the launch: the census words, a counter per 256-row panel (c_fc tiles
+                          // stored), a counter per 128-row half (c_proj tiles stored: the tail)
     int* err;             // host-mapped
     int ch;               // 256-row panels of an XCD per chunk
     int fc_slots;         // slots per XCD that run c_fc tiles (the others start with c_proj, i.e. wait)
@@ -198,11 +211,34 @@ struct MlpPairArgs {
 // global_ accesses, which also count in lgkmcnt: every fetch segment behind an epilogue then waits for the tile's stores, +19 us), and
 // a loop around the two bodies (c_fc in several segments with c_proj between them - built, and no faster in any order:
 // profiles/r06_mlp_pair.txt) makes both problems worse.  Hence: compact by-value arguments, straight-line code, c_fc then c_proj.
-template <int HL>
-__global__ __launch_bounds__(512, 2) void mlp_pair_kernel(const MlpPairArgs P) {
+// c_proj's arguments are read from the kernel-argument segment BEHIND the c_fc body (as kernel arguments proper they are loaded at the
+// kernel's entry and sit in 30 scalar registers all through c_fc: with the text tower's three more - gamma, out3, ld3 - that is what
+// tips the allocator over, see above).  Read back as integers the pointers have lost their address space; a cast of the BITS to an
+// address-space-1 pointer gives it back (a cast of the generic pointer there and back is folded away and leaves flat_ accesses).
+template <class T>
+__device__ __forceinline__ T load_kernarg(unsigned offset) {
+    static_assert(sizeof(T) % 4 == 0, "dword-sized arguments");
+    const __attribute__((address_space(4))) char* ka = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    const __attribute__((address_space(4))) unsigned* w = reinterpret_cast<const __attribute__((address_space(4))) unsigned*>(ka + offset);
+    unsigned t[sizeof(T) / 4];
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) t[i] = w[i];
+    T o;
+    __builtin_memcpy(&o, t, sizeof(T));
+    return o;
+}
+template <class T>
+__device__ __forceinline__ T* global_bits(T* p) {
+    return (T*)(__attribute__((address_space(1))) T*)(unsigned long long)p;
+}
+
+template <int HL, bool GS>
+__global__ __launch_bounds__(512, 2) void mlp_pair_kernel(const MlpPairArgs P_in) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // this workgroup's XCD (the hardware's word, not blockIdx's) and its work slot there
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const MlpPairArgs& P = P_in;
     MlpGeom geo;
     geo.xcd = (int)(__builtin_amdgcn_s_getreg(20 /* HW_REG_XCC_ID */ | (0 << 6) | ((4 - 1) << 11)) & (MLP_NX - 1));
     geo.cpx = gridDim.x / MLP_NX;
@@ -236,7 +272,8 @@ __global__ __launch_bounds__(512, 2) void mlp_pair_kernel(const MlpPairArgs P) {
 #endif
     }
     {
-        MlpProjSched sp(geo, P.proj.M, P.proj.N, P.proj.K, P.ready + MLP_CENSUS, P.err);
+        const MlpProjArgs Q = load_kernarg<MlpProjArgs>((unsigned)__builtin_offsetof(MlpPairArgs, proj));      // (here, not at the kernel's entry)
+        MlpProjSched sp(geo, Q.M, Q.N, Q.K, P.ready + MLP_CENSUS, P.err);
         sp.e0 = 0; sp.n = sp.total;
 #ifdef HG_PAIR_EXP
         if (P.only == 2) sp.target = 0u;
@@ -244,13 +281,46 @@ __global__ __launch_bounds__(512, 2) void mlp_pair_kernel(const MlpPairArgs P) {
 #endif
         if (sp.n > 0) {
             GemmArgs a{};
-            a.A = P.proj.A; a.W = P.proj.W; a.bias = P.proj.bias; a.out = P.proj.out; a.mu = P.proj.mu; a.out2 = P.proj.out2;
-            a.stats = P.proj.stats; a.lo = P.proj.lo; a.muc = P.proj.muc;
-            a.lda = P.proj.lda; a.ldc = P.proj.ldc; a.ld2 = P.proj.ld2; a.M = P.proj.M; a.N = P.proj.N; a.K = P.proj.K;
-            a.stats_ld = P.proj.stats_ld;
+            a.A = global_bits(Q.A); a.W = global_bits(Q.W); a.bias = global_bits(Q.bias); a.out = global_bits(Q.out); a.mu = global_bits(Q.mu);
+            a.out2 = global_bits(Q.out2); a.stats = global_bits(Q.stats); a.lo = global_bits(Q.lo); a.muc = global_bits(Q.muc);
+            a.lda = Q.lda; a.ldc = Q.ldc; a.ld2 = Q.ld2; a.M = Q.M; a.N = Q.N; a.K = Q.K;
+            a.stats_ld = Q.stats_ld;
+            if constexpr (GS) { a.gamma = global_bits(Q.gamma); a.out3 = global_bits(Q.out3); a.ld3 = Q.ld3; }
             __builtin_amdgcn_s_waitcnt(0xC07F);
             barrier_raw();      // every wave has left the c_fc body (its LDS image is dead)
-            gemm_ring2_body<EPI_RESID_LN_F32, HL, false>(a, a.N / 256, P.proj.a_bytes, 0, sp);
+            gemm_ring2_body<EPI_RESID_LN_F32, HL, GS>(a, a.N / 256, Q.a_bytes, 0, sp);
+        }
+        // ---- tail: the LayerNorm statistics of the updated rows (what finalize_stats does in a launch of its own).  The column tiles of
+        // a 128-row half ran on workgroups of THIS XCD; each of them, with its tile's partial sums in the XCD's L2 (every wave has drained
+        // its stores), adds 1 to the half's counter, and the one whose add comes last combines the rows' partial sums - the same
+        // function, the same bits.  Nothing here touches the K loops: a workgroup does it once, behind its last tile.
+        const MlpFinArgs F = load_kernarg<MlpFinArgs>((unsigned)__builtin_offsetof(MlpPairArgs, fin));
+        if (F.mr != nullptr) {
+            wait_vm<0>();
+            __syncthreads();
+            const int tid = mlp_thread_id(geo.wave);      // (not threadIdx.x: see thread_id())
+            const int M = Q.M, nt = Q.stats_ld, tn = Q.N / 256;
+            unsigned* const done = P.ready + MLP_CENSUS + (M + 255) / 256;
+            int* const slot_word = reinterpret_cast<int*>(smem + P.census_off);
+            float* const stats = global_bits(Q.stats);
+            float* const f_mr = global_bits(F.mr);
+            float* const f_mu = global_bits(F.mu);
+            float* const f_muc = global_bits(F.muc);
+            // all of this workgroup's counter adds at once (lane e of wave 0: tile e), their answers through LDS: one atomic round trip
+            int* const lastw = reinterpret_cast<int*>(smem);      // (the ring's first bytes: the bodies are done)
+            if (tid < sp.n) {
+                int tm, t2;
+                sp.tile(tid, tm, t2);
+                lastw[tid] = (int)__hip_atomic_fetch_add(done + tm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tn - 1 ? tm : -1;
+            }
+            __syncthreads();
+            (void)slot_word;
+            for (int e = 0; e < sp.n; ++e) {
+                const int tm = lastw[e];      // the row half this workgroup finalises, or -1
+                const int m = tm * 128 + (tid & 127);
+                if (tm >= 0 && tid < 128 && m < M)
+                    finalize_stats_row<true>(stats + (size_t)m * nt * 2, f_mr, f_mu, f_muc, m, nt, 64, 0, global_bits(F.range_flag));
+            }
         }
 #ifdef HG_PAIR_EXP
         t_stamp[2] = __builtin_amdgcn_s_memtime();
@@ -271,30 +341,30 @@ bool mlp_pair_ok(const GemmArgs& fc, const GemmArgs& proj, int n_cu) {
     if (fc.M != proj.M || proj.K != fc.N || proj.lda != fc.ldc || (const void*)proj.A != fc.out) return false;
     if (fc.K < 5 * 64 || proj.K < 8 * 64) return false;                    // K-tile kinds of the two hand-off protocols
     if ((size_t)((fc.M + 255) / 256) * 256 * fc.ldc * 2 >= (1ull << 32)) return false;      // fc through one buffer descriptor
-    if (proj.gamma || fc.M < 8 * 256) return false;
-    // (hl 3 - the stream leaves as fp32: one c_proj per tower on the class-rows path - stays two launches: its instance of this kernel needs
-    // five more scalar registers than the others, spills 13, and that is where the scheduler gives the c_fc epilogue up: see the kernel)
-    return proj.hl == 0 || proj.hl == 2;
+    if (fc.M < 8 * 256) return false;
+    // (the text tower: the next LayerNorm's weight in the activation copy - beside the stream's hi half where the stream leaves as hi / lo)
+    if (proj.gamma && proj.hl == 2 && (!proj.out3 || proj.ld3 < proj.N || (proj.ld3 % 8))) return false;
+    return proj.hl == 0 || proj.hl == 2 || proj.hl == 3;
 }
 
-template <int HL>
+template <int HL, bool GS = false>
 static hipError_t launch_pair_t(const MlpPairArgs& a, int grid, int lds, hipStream_t s) {
     static bool attr_set_d[HG_MAX_DEVICES] = {};
     bool& attr_set = attr_set_d[current_device_index()];
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_pair_kernel<HL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_pair_kernel<HL, GS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((mlp_pair_kernel<HL>), dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((mlp_pair_kernel<HL, GS>), dim3(grid), dim3(512), lds, s, a);
     return hipGetLastError();
 }
 
-size_t mlp_pair_ready_words(int M) { return (size_t)MLP_CENSUS + (size_t)((M + 255) / 256); }
+size_t mlp_pair_ready_words(int M) { return (size_t)MLP_CENSUS + (size_t)((M + 255) / 256) + (size_t)((M + 127) / 128); }
 
 hipError_t launch_mlp_pair(const GemmArgs& fc, const GemmArgs& proj_in, unsigned* ready, int* err, int ch, int fc_slots, int n_cu,
-                           hipStream_t s) {
+                           hipStream_t s, float* fin_mr, float* fin_mu, float* fin_muc, int* range_flag) {
     GemmArgs proj = proj_in;
     if (!proj.ld2) proj.ld2 = proj.ldc;
     if (!mlp_pair_ok(fc, proj, n_cu) || !ready || !err || proj.ld2 % 8) return hipErrorInvalidValue;
@@ -304,7 +374,9 @@ hipError_t launch_mlp_pair(const GemmArgs& fc, const GemmArgs& proj_in, unsigned
                      (unsigned)((size_t)((fc.M + 255) / 256) * 256 * fc.lda * 2)};
     a.proj = MlpProjArgs{proj.A, proj.W, proj.bias, (float*)proj.out, proj.mu, proj.out2, proj.stats, proj.lo, proj.muc,
                          proj.lda, proj.ldc, proj.ld2, proj.M, proj.N, proj.K, proj.stats_ld,
-                         (unsigned)((size_t)((proj.M + 127) / 128) * 128 * proj.lda * 2)};
+                         (unsigned)((size_t)((proj.M + 127) / 128) * 128 * proj.lda * 2), proj.gamma, proj.out3, proj.ld3};
+    a.fin = MlpFinArgs{fin_mr, fin_mu, fin_muc, range_flag};
+    if (fin_mr && (!fin_mu || fin_mu != proj.mu)) return hipErrorInvalidValue;      // (the centre the copy is written with IS the previous mean)
     a.ready = ready; a.err = err;
     a.ch = ch < 1 ? 1 : (ch > 64 ? 64 : ch);
     a.fc_slots = fc_slots < 1 ? 1 : fc_slots;
@@ -313,7 +385,7 @@ hipError_t launch_mlp_pair(const GemmArgs& fc, const GemmArgs& proj_in, unsigned
     a.only = only_env;
 #endif
     const int lds_fc = 2 * (2 * 4 * 4096 + 2 * 16384) + fc.N * 4 * 2 + 256 * 8;
-    const int lds_proj = 3 * 49152 + proj.N * 4;
+    const int lds_proj = 3 * 49152 + proj.N * 4 * (proj.gamma ? 2 : 1);
     a.census_off = lds_fc > lds_proj ? lds_fc : lds_proj;      // (behind both bodies' LDS images: never overwritten)
     const int lds = a.census_off + 16;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -348,9 +420,17 @@ hipError_t launch_mlp_pair(const GemmArgs& fc, const GemmArgs& proj_in, unsigned
         return e;
     }
 #endif
+    if (proj.gamma) {
+        switch (proj.hl) {
+            case 2: return launch_pair_t<2, true>(a, grid, lds, s);
+            case 3: return launch_pair_t<3, true>(a, grid, lds, s);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (proj.hl) {
         case 0: return launch_pair_t<0>(a, grid, lds, s);
         case 2: return launch_pair_t<2>(a, grid, lds, s);
+        case 3: return launch_pair_t<3>(a, grid, lds, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -267,11 +267,13 @@ int hg_vae_loss(hg_ctx*, const float* recon, const float* x, const float* mean, 
  *   "mlp_fused"       [HG_MLP_FUSED]       blocks of width 512 (the text tower, separate-LayerNorm path): 1 = c_fc -> QuickGELU -> c_proj ->
  *                      residual as ONE kernel (hg_vae_fused.hip mode 3: the [rows, 2048] activation stays on chip) for the leading rows that
  *                      fill whole rounds of 128-row items, 2 = every row, 0 (default: measured a tie) = the two GEMMs
- *   "mlp_pair"        [HG_MLP_PAIR]        1 (default): in the LayerNorm-folded blocks of the vision tower (variant A, stream held as hi / lo or fp32
- *                      throughout) c_fc -> QuickGELU -> c_proj run as ONE persistent launch (hoigen_amd/csrc/hg_mlp_pair.hip: the c_fc
+ *   "mlp_pair"        [HG_MLP_PAIR]        1 (default): in the LayerNorm-folded blocks of both towers (variant A; every form of the residual stream and
+ *                      of the LayerNorm weight) c_fc -> QuickGELU -> c_proj run as ONE persistent launch (hoigen_amd/csrc/hg_mlp_pair.hip: the c_fc
  *                      tiles publish per-256-row-panel ready counters, the c_proj tiles of a panel - on the same XCD by its hardware id -
  *                      wait for them; results do not depend on workgroup placement; a wait that times out makes the NEXT call return
- *                      HG_ERR_HIP; devices with 8 x 32 CUs, otherwise the two launches run); 0: two launches.  Bit-identical results.
+ *                      HG_ERR_HIP; devices with 8 x 32 CUs, otherwise the two launches run); 2: as 1, and the last workgroup of a row half also
+ *                      combines that half's LayerNorm partial sums (no finalize_stats launch between the blocks; measured slower in the
+ *                      vision tower, a tie in the text tower); 0: two launches.  Bit-identical results in all three.
  *   "mlp_pair_chunk"  [HG_MLP_PAIR_CHUNK]  1 .. 64: 256-row panels of an XCD per chunk of that launch's c_fc tile order (default 32: the XCD's whole list
  *                      column group by column group, as in the stand-alone kernel; speed only)
  *   "mlp_pair_fc_slots" [HG_MLP_PAIR_FC_SLOTS] 1 .. 64: workgroups per XCD (of 32) that run c_fc tiles in that launch (default 32); the others start with

@@ -41,9 +41,9 @@ def test_no_kernel_spills_registers_or_uses_scratch():
     assert len(kernels) >= 60, f"only {len(kernels)} kernels seen: the remarks were not parsed"
     # SGPR "spills" are v_writelane moves into spare VGPR lanes, not memory: tolerated only in the two fp32 fallback kernels of
     # the adapter (weights held in scalar registers by design: hg_adapter.hip), which no batch-256 path runs
-    sgpr_ok = ("adapter_kv_kernel", "adapter_decoder_kernel", "qkv_attn_kernel", "vae_fused_kernelILi0E", "mlp_pair_kernel")
-    # (mlp_pair_kernel, hg_mlp_pair.hip: two GEMM bodies' arguments and schedules in one kernel - a handful of scalars are parked in VGPR
-    # lanes between the bodies; what must not happen inside them is pinned by test_mlp_pair_kernel_codegen below)
+    sgpr_ok = ("adapter_kv_kernel", "adapter_decoder_kernel", "qkv_attn_kernel", "vae_fused_kernelILi0E", "mlp_pair_kernelILi2ELb1E")
+    # (mlp_pair_kernel<2, gamma>, hg_mlp_pair.hip - the text tower's instance: two GEMM bodies in one kernel, three scalars are parked in
+    # VGPR lanes around its tail; what must not happen inside the bodies is pinned by test_mlp_pair_kernel_codegen below)
     # (qkv_attn_kernel, hg_qkv_attn.hip, runs its K loop on 156 accumulator + 48 fragment registers and its attention phases beside
     # 78 registers of parked fp16 results: it used to park a handful of per-item values in scratch across the K loop; values the
     # allocator would keep live across the loop - a hoisted lane id of __shfl_xor, a hoisted `wave < 2`, a constant pair, the zero high
@@ -126,7 +126,8 @@ def test_mlp_pair_kernel_codegen():
       * no flat_ instruction (pointers that lost their address space: flat accesses count in lgkmcnt, every fetch segment behind an
         epilogue then waits for the tile's stores);
       * the QuickGELU epilogue block keeps its interleaved schedule (<= 100 s_nop; 242 when scalar-register spilling makes the
-        scheduler minimise pressure in every region);
+        scheduler minimise pressure in every region - c_proj's arguments are therefore read from the kernel-argument segment behind the
+        c_fc body, and get their address space back through a cast of their bits);
       * every MFMA operand tuple starts at a multiple of 4 registers (threadIdx.x kept alive in v0 across the bodies shifts them to 2 mod 4);
       * no lane moves of spilled scalars inside any block that issues MFMAs, no scratch anywhere."""
     with tempfile.TemporaryDirectory() as tmp:
@@ -136,7 +137,7 @@ def test_mlp_pair_kernel_codegen():
         assert r.returncode == 0, r.stderr[-3000:]
         txt = open(out).read()
     names = re.findall(r"^(_ZN2hg15mlp_pair_kernel\S+):", txt, re.M)
-    assert len(names) == 2, names
+    assert len(names) == 5, names      # stream fp32 / hi-lo / hi-lo -> fp32, and the text tower's two with gamma in the activation copy
     for name in names:
         i = txt.index(name + ":")
         body = txt[i:txt.index("s_endpgm", i)]
@@ -156,11 +157,8 @@ def test_mlp_pair_kernel_codegen():
         assert n_mfma == 640, (name, n_mfma)      # c_fc: 6 K-tile kinds x 64; c_proj: 8 x 32
         epilogues = [b for b in blocks if sum(1 for x in b if x.startswith("v_exp_f32")) >= 64]
         assert len(epilogues) == 1 and sum(1 for x in epilogues[0] if x.startswith("s_nop")) <= 100, name
-        # (the hi / lo instance - every launch of the default configuration - must have none; the fp32-stream instance, option
-        # stream_hilo = 0, needs a few more scalars for its fp32 stores and is allowed one lane read per K-tile block)
-        allowed = 0 if "ILi2E" in name else 1
         for b in blocks:
             if any(x.startswith("v_mfma") for x in b):
-                assert sum(1 for x in b if x.startswith(("v_readlane", "v_writelane"))) <= allowed, name
+                assert not any(x.startswith(("v_readlane", "v_writelane")) for x in b), name
         for m in re.finditer(r"v_mfma\S+ v\[(\d+):\d+\], v\[(\d+):\d+\], v\[(\d+):\d+\]", body):
             assert int(m.group(1)) % 4 == 0 and int(m.group(2)) % 4 == 0, (name, m.group(0))

@@ -83,8 +83,9 @@ def test_fused_in_proj_attention_is_bit_identical_inside_encode_image(fullA):
 
 def test_mlp_pair_one_launch_is_bit_identical_inside_encode_image(fullA):
     """Option mlp_pair (hg_mlp_pair.hip: c_fc -> QuickGELU -> c_proj of a block as ONE persistent launch, the c_fc tiles publishing
-    per-row-panel ready counters their c_proj tiles wait for): the same tiles, K loops and epilogues in another order and on other
-    workgroups, so encode_image gives the SAME bits as the two launches - at batch 256, 171 (ragged last panels) and 40 (fewer
+    per-row-panel ready counters their c_proj tiles wait for; the LayerNorm statistics of the updated rows combined in the launch's tail by
+    the last of a row half's column-tile workgroups): the same tiles, K loops, epilogues and statistics in another order and on other
+    workgroups, so encode_image gives the SAME bits as the two launches + finalize_stats - at batch 256, 171 (ragged last panels) and 40 (fewer
     c_proj tiles than two rounds), with several chunk sizes of the c_fc tile order and with 30 or 24 of an XCD's 32 workgroups running
     c_fc tiles (the others really wait for their first panels), every row of the last block or the class rows only; repeated launches
     agree (a race would show up as a difference); the reference's golden crops ride inside the batch."""
@@ -99,13 +100,13 @@ def test_mlp_pair_one_launch_is_bit_identical_inside_encode_image(fullA):
             for n in (256, 171, 40):
                 fullA.visual.set_option("mlp_pair", 0)
                 want = fullA.encode_image(crops[:n])
-                fullA.visual.set_option("mlp_pair", 1)
-                for chunk, slots in ((32, 32), (8, 30), (3, 24), (25, 30)):
+                for pair, chunk, slots in ((1, 32, 32), (2, 32, 32), (1, 8, 30), (1, 3, 24), (2, 25, 30)):
+                    fullA.visual.set_option("mlp_pair", pair)      # (1: finalize_stats' work in the launch's tail; 2: in a launch of its own)
                     fullA.visual.set_option("mlp_pair_chunk", chunk)
                     fullA.visual.set_option("mlp_pair_fc_slots", slots)
                     for rep in range(3 if n == 256 else 1):
                         got = fullA.encode_image(crops[:n])
-                        assert torch.equal(got, want), (row0, n, chunk, slots, rep, float((got - want).abs().max()))
+                        assert torch.equal(got, want), (row0, n, pair, chunk, slots, rep, float((got - want).abs().max()))
         got = fullA.encode_image(crops)[60:64].float().cpu().numpy()
         assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-3
     finally:
@@ -140,6 +141,36 @@ def test_generator_above_a_million_rows():
         assert rel < 1e-5, rel
     finally:
         vae.set_option("vae_fused", 1, d)
+
+
+def test_mlp_pair_in_the_text_tower_is_bit_identical(fullA):
+    """The same one-launch MLP in the text tower (width 512: c_fc 8 column tiles, c_proj 2; the next LayerNorm's weight rides in the
+    activation copy - the kernel's gamma instances; 46 200 rows at 77 tokens: a ragged last panel with one 128-row half) and in the
+    truncated tower the generation pipeline runs (13-16 tokens): encode_text equals the two launches bit for bit, for all three
+    text_ln_fold settings (0: separate LayerNorm kernels - no pair there, the switch must be harmless)."""
+    d = dev()
+    g0 = json.load(open(f"{G}/g0_tokens.json"))
+    rows = g0["hoi600"]["ids"]
+    ids = np.zeros((len(rows), 77), np.int64)
+    for i, r in enumerate(rows):
+        ids[i, :len(r)] = r
+    ids = torch.from_numpy(ids).to(d)
+    prev_fold, prev_trunc = fullA.get_option("text_ln_fold"), fullA.truncate_text
+    try:
+        for fold in (1, 2, 0):
+            fullA.set_option("text_ln_fold", fold)
+            for trunc in (False, True):
+                fullA.truncate_text = trunc
+                fullA.set_option("mlp_pair", 0)
+                want = fullA.encode_text(ids)
+                for pair in (1, 2):
+                    fullA.set_option("mlp_pair", pair)
+                    got = fullA.encode_text(ids)
+                    assert torch.equal(got, want), (fold, trunc, pair, float((got.float() - want.float()).abs().max()))
+    finally:
+        fullA.set_option("mlp_pair", 1)
+        fullA.set_option("text_ln_fold", prev_fold)
+        fullA.truncate_text = prev_trunc
 
 
 def test_config4_vae_100k_rows_equals_chunks():
