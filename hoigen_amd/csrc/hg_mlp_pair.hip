@@ -71,7 +71,11 @@ struct MlpFcSched {
     __device__ __forceinline__ MlpFcSched(const MlpGeom& g, int M, int N, unsigned* ready_) {
         x = g.xcd; cu = g.cu; fcs = g.fcs; ch = g.ch; wave = g.wave; ready = ready_;
         tn = N / 256;
+#ifdef HG_FC_CG      // (experiment: column tiles per group of the c_fc order)
+        cg = tn % HG_FC_CG == 0 ? HG_FC_CG : tn;
+#else
         cg = tn % 4 == 0 ? 4 : (tn % 3 == 0 ? 3 : tn);
+#endif
         const int pf = (M + 255) / 256;
         npx = pf > x ? (pf - x + MLP_NX - 1) / MLP_NX : 0;
         nfc = npx / ch;
