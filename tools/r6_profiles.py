@@ -20,7 +20,7 @@ power = json.loads(pl[-1]).get("power") if pl else None
 def load(d, counter):
     fs = glob.glob(os.path.join(O, d) + "/**/*counter_collection.csv", recursive=True)
     agg, cnt = collections.defaultdict(float), collections.Counter()
-    for r in csv.DictReader(open(fs[0])):
+    for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):      # (gpurun merges: older passes may still lie beside the newest)
         if r["Counter_Name"] != counter:
             continue
         k = re.sub(r"\(.*", "", re.sub(r"^void hg::", "", r["Kernel_Name"]))[:48]
