@@ -83,8 +83,8 @@ def test_fused_in_proj_attention_is_bit_identical_inside_encode_image(fullA):
 
 def test_mlp_pair_one_launch_is_bit_identical_inside_encode_image(fullA):
     """Option mlp_pair (hg_mlp_pair.hip: c_fc -> QuickGELU -> c_proj of a block as ONE persistent launch, the c_fc tiles publishing
-    per-row-panel ready counters their c_proj tiles wait for; the LayerNorm statistics of the updated rows combined in the launch's tail by
-    the last of a row half's column-tile workgroups): the same tiles, K loops, epilogues and statistics in another order and on other
+    per-row-panel ready counters their c_proj tiles wait for; with value 2 the LayerNorm statistics of the updated rows are combined in the
+    launch's tail by the last of a row half's column-tile workgroups): the same tiles, K loops, epilogues and statistics in another order and on other
     workgroups, so encode_image gives the SAME bits as the two launches + finalize_stats - at batch 256, 171 (ragged last panels) and 40 (fewer
     c_proj tiles than two rounds), with several chunk sizes of the c_fc tile order and with 30 or 24 of an XCD's 32 workgroups running
     c_fc tiles (the others really wait for their first panels), every row of the last block or the class rows only; repeated launches
@@ -101,7 +101,7 @@ def test_mlp_pair_one_launch_is_bit_identical_inside_encode_image(fullA):
                 fullA.visual.set_option("mlp_pair", 0)
                 want = fullA.encode_image(crops[:n])
                 for pair, chunk, slots in ((1, 32, 32), (2, 32, 32), (1, 8, 30), (1, 3, 24), (2, 25, 30)):
-                    fullA.visual.set_option("mlp_pair", pair)      # (1: finalize_stats' work in the launch's tail; 2: in a launch of its own)
+                    fullA.visual.set_option("mlp_pair", pair)      # (1: finalize_stats in a launch of its own; 2: its work in the pair launch's tail)
                     fullA.visual.set_option("mlp_pair_chunk", chunk)
                     fullA.visual.set_option("mlp_pair_fc_slots", slots)
                     for rep in range(3 if n == 256 else 1):
