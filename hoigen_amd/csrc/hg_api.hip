@@ -167,6 +167,7 @@ struct hg_ctx {
                                  // 2: finalize_stats of the next LayerNorm in the launch's tail as well
     int opt_mlp_pair_chunk = 32; // ... 256-row panels of an XCD per chunk
     int opt_mlp_pair_fc_slots = 32;  // ... workgroups per XCD that run c_fc tiles (the rest start with c_proj)
+    int opt_mlp_pair_fault = 0;      // fault injection for the tests: that launch goes out one workgroup short, so that a hand-off wait meets its bound
     int n_cu = 256;
     // sticky device->host flag (host-mapped): a hand-off wait inside the MLP pair kernel gave up (a workgroup of its grid never became
     // resident); the call in flight returned garbage, the next tower call reports HG_ERR_HIP
@@ -946,7 +947,7 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
                     const bool fin = c->opt_mlp_pair == 2;
                     HG_HIP(launch_mlp_pair(g, pq, (unsigned*)c->pair_ready.p + i * (size_t)pair_panels, c->pair_err,
                                            c->opt_mlp_pair_chunk, c->opt_mlp_pair_fc_slots, c->n_cu, s, fin ? mr : nullptr, mu, muc,
-                                           c->range_flag));
+                                           c->range_flag, c->opt_mlp_pair_fault));
                     paired = true;
                     pair_fin = fin;
                 }
@@ -1121,7 +1122,8 @@ hg_ctx* hg_create(int device) {
                                                            {"HG_QKV_ATTN", "qkv_attn"}, {"HG_QKV_ATTN_MIN_SEQ", "qkv_attn_min_seq"},
                                                            {"HG_QKV_ATTN_GSZ", "qkv_attn_gsz"}, {"HG_QKV_ATTN_C", "qkv_attn_c"}, {"HG_TEXT_LN_FOLD", "text_ln_fold"}, {"HG_VAE_FUSED", "vae_fused"}, {"HG_MLP_FUSED", "mlp_fused"},
                                                            {"HG_MLP_PAIR", "mlp_pair"},
-                                                           {"HG_MLP_PAIR_CHUNK", "mlp_pair_chunk"}, {"HG_MLP_PAIR_FC_SLOTS", "mlp_pair_fc_slots"}};
+                                                           {"HG_MLP_PAIR_CHUNK", "mlp_pair_chunk"}, {"HG_MLP_PAIR_FC_SLOTS", "mlp_pair_fc_slots"},
+                                                           {"HG_MLP_PAIR_FAULT", "mlp_pair_fault"}};
     for (auto& o : init)
         if (const char* e = getenv(o.env)) (void)hg_set_option(c, o.key, atoi(e));      // (out-of-range values are ignored)
     c->err.clear();
@@ -1175,6 +1177,9 @@ int hg_set_option(hg_ctx* c, const char* key, int value) {
     } else if (k == "mlp_pair_fc_slots") {
         if (value < 1 || value > 64) return fail(c, HG_ERR_INVALID, "mlp_pair_fc_slots must be 1 .. 64 (got %d)", value);
         c->opt_mlp_pair_fc_slots = value;
+    } else if (k == "mlp_pair_fault") {
+        if (value < 0 || value > 1) return fail(c, HG_ERR_INVALID, "mlp_pair_fault must be 0 or 1 (got %d)", value);
+        c->opt_mlp_pair_fault = value;
     }
     else return fail(c, HG_ERR_INVALID, "unknown option '%s'", key);
     return HG_OK;
@@ -1200,6 +1205,7 @@ int hg_get_option(hg_ctx* c, const char* key, int* value) {
     else if (k == "mlp_pair") *value = c->opt_mlp_pair;
     else if (k == "mlp_pair_chunk") *value = c->opt_mlp_pair_chunk;
     else if (k == "mlp_pair_fc_slots") *value = c->opt_mlp_pair_fc_slots;
+    else if (k == "mlp_pair_fault") *value = c->opt_mlp_pair_fault;
     else return fail(c, HG_ERR_INVALID, "unknown option '%s'", key);
     return HG_OK;
 }

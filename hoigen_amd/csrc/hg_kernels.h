@@ -109,7 +109,8 @@ size_t mlp_pair_ready_words(int M);
 // fin_mr (optional): the launch also does finalize_stats' work for the rows c_proj updates - mr / mu / muc / range_flag as in
 // launch_finalize_stats (mu must be proj.mu) - in its tail; null: the caller launches finalize_stats
 hipError_t launch_mlp_pair(const GemmArgs& fc, const GemmArgs& proj, unsigned* ready, int* err, int ch, int fc_slots, int n_cu, hipStream_t s,
-                           float* fin_mr = nullptr, float* fin_mu = nullptr, float* fin_muc = nullptr, int* range_flag = nullptr);
+                           float* fin_mr = nullptr, float* fin_mu = nullptr, float* fin_muc = nullptr, int* range_flag = nullptr,
+                           int grid_short = 0);      // grid_short (fault injection: hg_api.hip option mlp_pair_fault): workgroups NOT launched
 // two 4-wave workgroups per CU, 128x256 tiles, free-running (hg_gemm_duo.hip): residual GEMMs and fp16/fp32 outputs
 bool gemm_duo_ok(int epi, const GemmArgs& a);
 hipError_t launch_gemm_duo(int epi, const GemmArgs& a, hipStream_t s);

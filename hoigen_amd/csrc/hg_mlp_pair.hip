@@ -20,7 +20,7 @@
 // (HW_REG_XCC_ID) and takes the next free work slot OF THAT XCD from a census counter; XCD x's slots own the row panels p = x (mod 8),
 // their c_fc tiles and their c_proj tiles.  So results do not depend on where or when workgroups land.  Progress needs every slot
 // taken, i.e. gridDim / 8 workgroups on each XCD - what one workgroup per CU on the whole chip gives (the launcher refuses other
-// devices); a workgroup beyond its XCD's slots exits, and a wait that outlasts its bound (~2 s: a slot nobody took) sets *err - a
+// devices); a workgroup beyond its XCD's slots exits, and a wait that outlasts its bound (~0.6 s: a slot nobody took) sets *err - a
 // host-mapped word the API turns into HG_ERR_HIP - and goes on with whatever is there: wrong results behind an error, never a hang.
 // Within a workgroup every c_fc tile precedes the c_proj tiles that could wait for it, so resident workgroups always progress.
 // (The launch wants the GPU to itself - one process per GPU, one stream of the library: two such launches from different streams or
@@ -41,7 +41,7 @@
 
 namespace hg {
 
-constexpr int MLP_SPIN_LIMIT = 1 << 20;    // polls of a ready counter (~2 us each) before giving up
+constexpr int MLP_SPIN_LIMIT = 1 << 20;    // polls of a ready counter (~0.5 us each: s_sleep 16) before giving up
 constexpr int MLP_NX = 8;                  // XCDs (HW_REG_XCC_ID 0 .. 7)
 constexpr int MLP_CENSUS = 16;             // words in front of the ready counters: [0, 8) work slots taken per XCD
 
@@ -163,6 +163,8 @@ struct MlpProjSched {
         for (int it = 0; it < MLP_SPIN_LIMIT; ++it) {
             if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return;
             __builtin_amdgcn_s_sleep(16);
+            // (a wait of this launch or an earlier one has already given up: the call is lost, do not sit out the bound tile after tile)
+            if ((it & 1023) == 1023 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
         }
         __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // never a hang: flag it and go on
     }
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(512, 2) void mlp_pair_kernel(const MlpPairArgs P_in
     const MlpPairArgs& P = P_in;
     MlpGeom geo;
     geo.xcd = (int)(__builtin_amdgcn_s_getreg(20 /* HW_REG_XCC_ID */ | (0 << 6) | ((4 - 1) << 11)) & (MLP_NX - 1));
-    geo.cpx = gridDim.x / MLP_NX;
+    geo.cpx = (gridDim.x + MLP_NX - 1) / MLP_NX;      // (slots per XCD; a grid launched short - the API's fault-injection option - leaves a slot untaken)
     geo.wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     geo.ch = P.ch;
     geo.fcs = P.fc_slots < geo.cpx ? P.fc_slots : geo.cpx;
@@ -370,7 +372,7 @@ static hipError_t launch_pair_t(const MlpPairArgs& a, int grid, int lds, hipStre
 size_t mlp_pair_ready_words(int M) { return (size_t)MLP_CENSUS + (size_t)((M + 255) / 256) + (size_t)((M + 127) / 128); }
 
 hipError_t launch_mlp_pair(const GemmArgs& fc, const GemmArgs& proj_in, unsigned* ready, int* err, int ch, int fc_slots, int n_cu,
-                           hipStream_t s, float* fin_mr, float* fin_mu, float* fin_muc, int* range_flag) {
+                           hipStream_t s, float* fin_mr, float* fin_mu, float* fin_muc, int* range_flag, int grid_short) {
     GemmArgs proj = proj_in;
     if (!proj.ld2) proj.ld2 = proj.ldc;
     if (!mlp_pair_ok(fc, proj, n_cu) || !ready || !err || proj.ld2 % 8) return hipErrorInvalidValue;
@@ -395,7 +397,7 @@ hipError_t launch_mlp_pair(const GemmArgs& fc, const GemmArgs& proj_in, unsigned
     a.census_off = lds_fc > lds_proj ? lds_fc : lds_proj;      // (behind both bodies' LDS images: never overwritten)
     const int lds = a.census_off + 16;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    const int grid = n_cu;
+    const int grid = n_cu - (grid_short > 0 && grid_short < MLP_NX ? grid_short : 0);
 #ifdef HG_PAIR_EXP
     static int dbg_left = []() { const char* e = getenv("HG_PAIR_DBG"); return e ? atoi(e) : 0; }();
     if (dbg_left > 0 && proj.hl == 2) {

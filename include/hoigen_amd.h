@@ -279,6 +279,9 @@ int hg_vae_loss(hg_ctx*, const float* recon, const float* x, const float* mean, 
  *                      column group by column group, as in the stand-alone kernel; speed only)
  *   "mlp_pair_fc_slots" [HG_MLP_PAIR_FC_SLOTS] 1 .. 64: workgroups per XCD (of 32) that run c_fc tiles in that launch (default 32); the others start with
  *                      their c_proj tiles, i.e. sleep until the first row panels are complete (speed only)
+ *   "mlp_pair_fault"  [HG_MLP_PAIR_FAULT]  test hook, default 0.  1: that launch goes out one workgroup short - a work slot nobody takes -, so that the
+ *                      hand-off waits that depend on it meet their bound (~0.6 s), the results of the call are wrong and the NEXT call returns
+ *                      HG_ERR_HIP (tests/test_gpu_scale.py exercises "an error, never a hang" with it, and the recovery once it is 0 again)
  *   "chunk_rows"      [HG_CHUNK_ROWS]      rows per VAE / mlp_net / cache-logits chunk (>= 256; default 32768; the last chunk of a
  *                      call absorbs a tail of up to an eighth of it)
  * Unknown keys and out-of-range values return HG_ERR_INVALID. */

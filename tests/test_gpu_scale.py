@@ -143,6 +143,36 @@ def test_generator_above_a_million_rows():
         vae.set_option("vae_fused", 1, d)
 
 
+def test_mlp_pair_wait_that_cannot_end_is_an_error_not_a_hang(fullA):
+    """The c_proj tiles of the MLP pair launch wait for other workgroups of the same launch (hg_mlp_pair.hip).  Option mlp_pair_fault = 1
+    sends that launch out one workgroup short: a work slot of one XCD stays untaken, its c_fc tiles are never produced, the row panels
+    they belong to never become complete.  What must happen: the waits give up at their bound (~0.6 s for the first, the others as soon as
+    they see the error word), the call comes back - with wrong rows, it cannot be failed without a synchronisation -, the NEXT call
+    fails with HG_ERR_HIP (RuntimeError) and consumes the report; with the option back at 0 the same context gives the same bits as
+    before.  Never a hang, never a silent wrong answer."""
+    import time
+    d = dev()
+    x = torch.randn(40, 3, 224, 224, device=d, generator=torch.Generator(device=d).manual_seed(31))
+    v = fullA.visual
+    want = fullA.encode_image(x).clone()
+    torch.cuda.synchronize()
+    v.set_option("mlp_pair_fault", 1)
+    try:
+        t0 = time.time()
+        fullA.encode_image(x)
+        torch.cuda.synchronize()
+        took = time.time() - t0
+        print(f"\nencode_image with one workgroup of every pair launch missing came back after {took:.1f} s")
+        assert took < 120, "the bounded waits did not end"
+        with pytest.raises(RuntimeError, match="hand-off wait inside the MLP pair kernel"):
+            fullA.encode_image(x)
+    finally:
+        v.set_option("mlp_pair_fault", 0)
+    torch.cuda.synchronize()
+    again = fullA.encode_image(x)
+    assert torch.equal(again, want), "the context did not recover after the reported fault"
+
+
 def test_mlp_pair_in_the_text_tower_is_bit_identical(fullA):
     """The same one-launch MLP in the text tower (width 512: c_fc 8 column tiles, c_proj 2; the next LayerNorm's weight rides in the
     activation copy - the kernel's gamma instances; 46 200 rows at 77 tokens: a ragged last panel with one 128-row half) and in the
