@@ -664,6 +664,7 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
     if (row0_out) *row0_out = nullptr;
     if (c->pair_err && *(volatile int32_t*)c->pair_err) {
         *(volatile int32_t*)c->pair_err = 0;
+        if (c->range_flag) *(volatile int32_t*)c->range_flag = 0;      // (whatever that call's rows overflowed into is part of the same report)
         return fail(c, HG_ERR_HIP, "a hand-off wait inside the MLP pair kernel of a previous call timed out (a workgroup of its grid never "
                                    "became resident): that call's outputs are invalid; set option mlp_pair = 0 if this device cannot "
                                    "hold one workgroup per compute unit");
