@@ -19,6 +19,7 @@
 #include <vector>
 
 #include <algorithm>
+#include <mutex>
 
 #include "../../include/hoigen_amd.h"
 #include "hg_kernels.h"
@@ -230,6 +231,41 @@ struct DevGuard {
 inline void keep_first(int& rc, int r) {
     if (!rc) rc = r;
 }
+
+// The MLP pair launch (hg_mlp_pair.hip) has one workgroup per CU and its workgroups wait for each other: two such launches from different
+// streams of this process, each holding part of the CUs, would wait for each other until their bound (both towers of a model run it, and a
+// caller may well encode text on one stream and crops on another).  As long as every pair launch of a device comes from ONE stream
+// nothing is done.  The first time a second stream shows up the device is synchronised once, and from then on every pair launch waits for
+// the previous one's event and records its own: the launches are serial across streams (each fills the chip anyway).  Other processes
+// on the same GPU are the deployment's business (option mlp_pair = 0 there).
+struct PairGate {
+    std::mutex mu;
+    bool have_first = false, multi = false, evt_set = false;
+    hipStream_t first = nullptr;
+    hipEvent_t evt = nullptr;
+};
+static PairGate g_pair_gate[16];
+struct PairGateScope {      // around ONE pair launch on stream s of device dev (the current device)
+    PairGate* g;
+    hipStream_t s;
+    PairGateScope(int dev, hipStream_t s_) : g(&g_pair_gate[dev & 15]), s(s_) {
+        g->mu.lock();
+#ifdef HG_NO_PAIR_GATE      // (experiment build: what two streams do to each other without the gate)
+        return;
+#endif
+        if (!g->have_first) { g->first = s; g->have_first = true; }
+        else if (!g->multi && s != g->first) {
+            (void)hipDeviceSynchronize();      // (once: whatever the first stream has in flight carries no event)
+            if (hipEventCreateWithFlags(&g->evt, hipEventDisableTiming) != hipSuccess) g->evt = nullptr;
+            g->multi = true;
+        }
+        if (g->multi && g->evt && g->evt_set) (void)hipStreamWaitEvent(s, g->evt, 0);
+    }
+    ~PairGateScope() {
+        if (g->multi && g->evt && hipEventRecord(g->evt, s) == hipSuccess) g->evt_set = true;
+        g->mu.unlock();
+    }
+};
 
 int ensure(hg_ctx* c, Buf& b, size_t bytes) {
     if (b.bytes >= bytes) return HG_OK;
@@ -942,6 +978,7 @@ int run_blocks(hg_ctx* c, const std::vector<BlockW>& blocks, int n_seq, int L, i
                 gs_args(pq, blocks[i + 1].ln1_w);
                 pq_built = true;
                 if (mlp_pair_ok(g, pq, c->n_cu)) {
+                    PairGateScope gate(c->device, s);
                     ProfScope ps(c, s, HG_PROF_MLP_PAIR, M, 4 * D, D);
                     // (option mlp_pair = 2: the launch's tail also does finalize_stats' work - measured +10 us on the launch for the 5 us
                     // launch it removes in the vision tower, a tie in the text tower (profiles/r06_mlp_pair.txt item 8); 1: its own launch)

@@ -23,8 +23,8 @@
 // devices); a workgroup beyond its XCD's slots exits, and a wait that outlasts its bound (~0.6 s: a slot nobody took) sets *err - a
 // host-mapped word the API turns into HG_ERR_HIP - and goes on with whatever is there: wrong results behind an error, never a hang.
 // Within a workgroup every c_fc tile precedes the c_proj tiles that could wait for it, so resident workgroups always progress.
-// (The launch wants the GPU to itself - one process per GPU, one stream of the library: two such launches from different streams or
-// processes that each hold part of the CUs wait for each other until the bound expires; INTEGRATION.md says so, option mlp_pair = 0.)
+// (The launch wants the GPU to itself: two such launches that each hold part of the CUs wait for each other until the bound expires.
+// Across the streams of one process hg_api.hip orders them (PairGate); across processes INTEGRATION.md says so, option mlp_pair = 0.)
 //
 // Tile order.  XCD x walks its panels p = x + 8 k in CHUNKS of `ch` panels: inside a chunk the c_fc tiles run column group by column
 // group (4 column tiles: their W slices stay in the XCD's L2 while the chunk's A panels stream, as in the stand-alone kernel's list);

@@ -271,8 +271,9 @@ int hg_vae_loss(hg_ctx*, const float* recon, const float* x, const float* mean, 
  *                      of the LayerNorm weight) c_fc -> QuickGELU -> c_proj run as ONE persistent launch (hoigen_amd/csrc/hg_mlp_pair.hip: the c_fc
  *                      tiles publish per-256-row-panel ready counters, the c_proj tiles of a panel - on the same XCD by its hardware id -
  *                      wait for them; results do not depend on workgroup placement; a wait that times out makes the NEXT call return
- *                      HG_ERR_HIP; devices with 8 x 32 CUs, otherwise the two launches run; the launch's workgroups wait for each other: a GPU
- *                      shared between streams or processes that both run it can hold both up until that bound - set 0 there); 2: as 1, and the last workgroup of a row half also
+ *                      HG_ERR_HIP; devices with 8 x 32 CUs, otherwise the two launches run; the launch's workgroups wait for each other: the library
+ *                      orders such launches across the streams of one process; PROCESSES that share a GPU and both run it can hold each other up
+ *                      until that bound - set 0 there); 2: as 1, and the last workgroup of a row half also
  *                      combines that half's LayerNorm partial sums (no finalize_stats launch between the blocks; measured slower in the
  *                      vision tower, a tie in the text tower); 0: two launches.  Bit-identical results in all three.
  *   "mlp_pair_chunk"  [HG_MLP_PAIR_CHUNK]  1 .. 64: 256-row panels of an XCD per chunk of that launch's c_fc tile order (default 32: the XCD's whole list

@@ -173,6 +173,45 @@ def test_mlp_pair_wait_that_cannot_end_is_an_error_not_a_hang(fullA):
     assert torch.equal(again, want), "the context did not recover after the reported fault"
 
 
+def test_mlp_pair_launches_from_two_streams_do_not_wait_for_each_other(fullA, g0):
+    """Both towers run the MLP pair launch, whose 256 workgroups wait for each other: if encode_image on one stream and encode_text on
+    another (two contexts) ever held part of the CUs each, both would sit out their bounds.  The library therefore serialises pair
+    launches of a device across streams from the moment a second stream shows up (hg_api.hip PairGate; tools/two_stream_pair_stress.py
+    is the long version of this test and ran clean with and without the gate - the gate closes a window, it does not fix a failure
+    that was seen): both calls give the bits of the single-stream calls, no wait gives up (the next calls do not raise), and the two
+    streams together take no longer than about the two calls one after the other."""
+    import time
+    from hoigen_amd import clip
+    d = dev()
+    x = torch.randn(64, 3, 224, 224, device=d, generator=torch.Generator(device=d).manual_seed(32))
+    ids = clip.tokenize(g0["hoi600"]["text"][:300]).to(d)
+    want_i, want_t = fullA.encode_image(x).clone(), fullA.encode_text(ids).clone()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(3):
+        fullA.encode_image(x); fullA.encode_text(ids)
+    torch.cuda.synchronize()
+    serial = (time.time() - t0) / 3
+    sa, sb = torch.cuda.Stream(device=d), torch.cuda.Stream(device=d)
+    sa.wait_stream(torch.cuda.current_stream(d)); sb.wait_stream(torch.cuda.current_stream(d))
+    outs = []
+    t0 = time.time()
+    for _ in range(6):
+        with torch.cuda.stream(sa):
+            a = fullA.encode_image(x)
+        with torch.cuda.stream(sb):
+            t = fullA.encode_text(ids)
+        outs.append((a, t))
+    torch.cuda.synchronize()
+    both = (time.time() - t0) / 6
+    print(f"\nencode_image(64) + encode_text(300): one stream {serial * 1e3:.2f} ms, two streams {both * 1e3:.2f} ms per pair of calls")
+    for a, t in outs:
+        assert torch.equal(a, want_i) and torch.equal(t, want_t)
+    assert both < 3 * serial + 0.05, "the two streams held each other up"
+    fullA.encode_image(x); fullA.encode_text(ids)      # (a wait that gave up would make these raise)
+    torch.cuda.synchronize()
+
+
 def test_mlp_pair_in_the_text_tower_is_bit_identical(fullA):
     """The same one-launch MLP in the text tower (width 512: c_fc 8 column tiles, c_proj 2; the next LayerNorm's weight rides in the
     activation copy - the kernel's gamma instances; 46 200 rows at 77 tokens: a ragged last panel with one 128-row half) and in the
