@@ -365,8 +365,14 @@ static hipError_t launch_pair_t(const MlpPairArgs& a, int grid, int lds, hipStre
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+#ifdef HG_PAIR_COOP      // (experiment: a cooperative launch - the runtime's co-residency guarantee - and what it costs per launch)
+    MlpPairArgs a2 = a;
+    void* args[] = {&a2};
+    return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&mlp_pair_kernel<HL, GS>), dim3(grid), dim3(512), args, (unsigned)lds, s);
+#else
     hipLaunchKernelGGL((mlp_pair_kernel<HL, GS>), dim3(grid), dim3(512), lds, s, a);
     return hipGetLastError();
+#endif
 }
 
 size_t mlp_pair_ready_words(int M) { return (size_t)MLP_CENSUS + (size_t)((M + 255) / 256) + (size_t)((M + 127) / 128); }
